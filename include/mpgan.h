@@ -1,0 +1,165 @@
+/*
+ * mpgan.h -- C ABI of the MI355X (gfx950) multi-pass GAN hot path.
+ *
+ * The reference (maxwerhahn/Multi-pass-GAN) is pure Python over TensorFlow 1.x
+ * and has no FFI of its own; every entry point below
+ * therefore names the TF / numpy / scipy call site it replaces.  Citations are
+ * relative to the reference tree.
+ *
+ * Conventions
+ *   - all tensors are dense NHWC float32 in device memory (HBM) unless noted;
+ *     pointers are borrowed, the caller (PyTorch-ROCm or any HIP program) owns
+ *     the memory;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *     on it and is re-entrant per stream;
+ *   - return value: MPG_OK or an MPG_ERR_* code; mpg_last_error() returns a
+ *     thread-local message for the last failing call.
+ */
+#ifndef MPGAN_H
+#define MPGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mpg_stream_t;
+
+enum { MPG_OK = 0, MPG_ERR_ARG = 1, MPG_ERR_HIP = 2, MPG_ERR_UNSUPPORTED = 3 };
+
+/* activation ids: tf.nn.relu / lrelu (tools_wscale/GAN.py:733-737) / tf.nn.tanh */
+enum { MPG_ACT_NONE = 0, MPG_ACT_RELU = 1, MPG_ACT_LRELU = 2, MPG_ACT_TANH = 3 };
+
+/* arithmetic of the MFMA convolution: fp16 operands, fp32 accumulation.
+ * F16X1: one fp16 term per operand (fast, ~3e-4 relative error per layer);
+ * F16X3: hi/lo fp16 split of both operands, three MFMA products
+ *        (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32-equivalent (~1e-6). */
+enum { MPG_PREC_F16X1 = 1, MPG_PREC_F16X3 = 3 };
+
+const char* mpg_last_error(void);
+/* library / device probe: returns MPG_OK when a gfx950 device is usable. */
+int mpg_device_info(int* cu_count, char* arch_name, int arch_name_len);
+const char* mpg_version(void);
+
+/* ------------------------------------------------------------------------
+ * Fused convolution  (replaces GAN.convolutional_layer = tf.nn.conv2d SAME +
+ * bias + batch_norm(inference) + activation, tools_wscale/GAN.py:80-119,686-691;
+ * the residual sum relu(convB(.) + conv1x1(.)) of resBlock,
+ * GAN/multipassGAN-4x.py:517-523, GAN/multipassGAN-out.py:227-235;
+ * GAN.pixel_norm, GAN.py:472-474; the nearest upsample in front of a block,
+ * GAN.py:501-523,541; the channel concat of x_in_2, multipassGAN-out.py:357.)
+ *
+ *   y = post( act( sum_s conv_SAME(up_s(x_s)[..., c_off_s : c_off_s+cin_s], W_s) + bias ) ) + post_add
+ *
+ * stride 1, SAME padding (pad_before = (k-1)/2, extra pad bottom/right).
+ * Each segment s contributes one K-slice of the implicit GEMM: a residual
+ * shortcut is a 1x1 segment, a channel concat is two segments with the same
+ * kernel size, a fused nearest upsample is up_log2 > 0.
+ * ------------------------------------------------------------------------ */
+#define MPG_MAX_SEG 4
+
+typedef struct mpg_conv_seg {
+    const float* x;      /* [N, H>>up_log2, W>>up_log2, cin_stride] */
+    const void*  wpack;  /* from mpg_conv_pack_weights, same prec/kc/ks as the launch */
+    int32_t cin;         /* channels consumed */
+    int32_t cin_stride;  /* channels per pixel of x */
+    int32_t c_off;       /* first channel consumed */
+    int32_t kh, kw;      /* kernel size, 1..7 */
+    int32_t up_log2;     /* fused nearest upsample: src = (y >> up_log2, x >> up_log2) */
+} mpg_conv_seg;
+
+typedef struct mpg_conv_desc {
+    int32_t n, h, w;          /* output batch / height / width */
+    int32_t cout;             /* 1..128 */
+    int32_t nseg;             /* 1..MPG_MAX_SEG */
+    mpg_conv_seg seg[MPG_MAX_SEG];
+    const float* bias;        /* [cout] effective bias (bias and folded batch norm) or NULL */
+    int32_t act;              /* MPG_ACT_* */
+    float   leak;             /* lrelu leak (0.2 in the reference) */
+    int32_t pixel_norm;       /* 1: y *= rsqrt(mean_c(y^2) + pn_eps) after act */
+    float   pn_eps;           /* 1e-8 */
+    const float* post_add;    /* optional [N,H,W,post_add_stride], channels post_add_coff.. added last */
+    int32_t post_add_stride;
+    int32_t post_add_coff;
+    float*  y;                /* [N,H,W,cout] */
+    int32_t prec;             /* MPG_PREC_* */
+    int32_t kc_max;           /* tuning: max input channels per LDS chunk (8,16,24,32); 0 = default */
+    int32_t ks;               /* tuning: k-steps (of 16) per weight stage (2 or 4); 0 = default */
+} mpg_conv_desc;
+
+/* bytes of the packed weight image of one segment. */
+size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec, int kc_max, int ks);
+
+/* Pack W[kh,kw,w_cin_total,cout] (HWIO fp32, device; GAN.py:93) channels
+ * [w_c_off, w_c_off+cin) into the MFMA fragment order, multiplying by the
+ * equalised-LR constant `wscale` (GAN.py:664-668) and an optional per-output
+ * channel scale (folded batch norm gamma/sqrt(var+eps), GAN.py:110). */
+int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw,
+                          int w_cin_total, int w_c_off, int cin, int cout,
+                          float wscale, const float* cout_scale,
+                          int prec, int kc_max, int ks, void* out, size_t out_bytes);
+
+int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* desc);
+
+/* Plain fp32 direct convolution on the vector ALUs, any stride / kernel /
+ * channel count (tf.nn.conv2d SAME, GAN.py:686-691; used for the strided
+ * discriminator convs GAN/multipassGAN-4x.py:607-614 and as an independent
+ * check of the MFMA kernel).  w is HWIO fp32, multiplied by wscale on the fly.
+ * y = act(conv(x, w*wscale) * cout_scale + bias). */
+int mpg_conv2d_direct(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
+                      const float* w_hwio, int kh, int kw, int cout, int stride_h, int stride_w,
+                      float wscale, const float* cout_scale, const float* bias,
+                      int act, float leak, float* y);
+
+/* ------------------------------------------------------------------------
+ * Resampling (legacy TF1 coordinates: src = dst * in/out, no half-pixel centres)
+ * ------------------------------------------------------------------------ */
+/* tf.image.resize_images(method=1) / kb.resize_images (GAN.py:517,541; multipassGAN-out.py:357) */
+int mpg_resize_nearest(mpg_stream_t stream, const float* x, int n, int h, int w, int c,
+                       float* y, int oh, int ow);
+/* tf.image.resize_images(method=0) (GAN.py:541) */
+int mpg_resize_bilinear(mpg_stream_t stream, const float* x, int n, int h, int w, int c,
+                        float* y, int oh, int ow);
+/* tf.image.resize_images(method=2): ResizeBicubic A=-0.75, 1/1024 weight table
+ * (avg_depool(mode=2), multipassGAN-out.py:330) */
+int mpg_resize_bicubic(mpg_stream_t stream, const float* x, int n, int h, int w, int c,
+                       float* y, int oh, int ow);
+/* tf.nn.avg_pool 2x2 VALID (GAN.py:162-169) */
+int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y);
+/* GAN.pixel_norm standalone (GAN.py:472-474) */
+int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, int c, float eps, float* y);
+/* y = act(a + b) elementwise (tf.nn.relu(tf.add(..)), multipassGAN-4x.py:523); b may be NULL */
+int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak, float* y);
+
+/* ------------------------------------------------------------------------
+ * Volume marshalling (generate3DUniForNewNetwork)
+ * ------------------------------------------------------------------------ */
+/* scipy.ndimage.zoom(v, factor on ONE axis, order=1, mode='constant')
+ * (multipassGAN-out.py:401-421,465-485,527-547; multipassGAN-4x.py:1095-1103):
+ * v viewed as [outer, n, inner] -> [outer, big, inner], src = o*(n-1)/(big-1). */
+int mpg_axis_zoom_linear(mpg_stream_t stream, const float* v, size_t outer, int n, size_t inner,
+                         float* out, int big);
+
+/* numpy transpose of a [d0,d1,d2,c] array to axes order perm (a permutation of
+ * 0,1,2; channels stay last), fused with the per-pass velocity channel
+ * permutation chan_map (out[..., k] = in[..., chan_map[k]], NULL = identity;
+ * multipassGAN-out.py:402-419,472-475) and the storage cutoff
+ * (x < cutoff -> 0, multipassGAN-out.py:614-615; cutoff <= 0 disables). */
+int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0, int d1, int d2, int c,
+                         const int* perm, const int* chan_map, float cutoff, float* out);
+
+/* add_adj_idcs channels (multipassGAN-out.py:423-436): out[i] = concat(in[i],
+ * in[i-1][...,0], in[i+1][...,0]) with zeros at the ends.  in: [s, hw, c] -> out: [s, hw, c+2].
+ * s_off/s_total let a rank build only its slice range of a sharded pass. */
+int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_total, size_t hw, int c,
+                     int s_off, int s_cnt, float* out);
+
+/* out[i] = v[i] < cutoff ? 0 : v[i]   (multipassGAN-4x.py:1156-1157) */
+int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPGAN_H */

@@ -1,0 +1,124 @@
+"""ctypes binding of libmpgan_hip.so (C ABI declared in include/mpgan.h).
+
+There is no CPU fallback: if the library is missing or no gfx950 device is
+present, every compute entry point raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmpgan_hip.so")
+
+MPG_OK = 0
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PREC_F16X1, PREC_F16X3 = 1, 3
+MAX_SEG = 4
+
+_ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH}
+
+
+def act_id(name):
+    try:
+        return _ACT_IDS[name]
+    except KeyError:
+        raise ValueError("unknown activation %r" % (name,))
+
+
+class MpgError(RuntimeError):
+    pass
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p),
+        ("wpack", ctypes.c_void_p),
+        ("cin", ctypes.c_int32),
+        ("cin_stride", ctypes.c_int32),
+        ("c_off", ctypes.c_int32),
+        ("kh", ctypes.c_int32),
+        ("kw", ctypes.c_int32),
+        ("up_log2", ctypes.c_int32),
+    ]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32),
+        ("h", ctypes.c_int32),
+        ("w", ctypes.c_int32),
+        ("cout", ctypes.c_int32),
+        ("nseg", ctypes.c_int32),
+        ("seg", ConvSeg * MAX_SEG),
+        ("bias", ctypes.c_void_p),
+        ("act", ctypes.c_int32),
+        ("leak", ctypes.c_float),
+        ("pixel_norm", ctypes.c_int32),
+        ("pn_eps", ctypes.c_float),
+        ("post_add", ctypes.c_void_p),
+        ("post_add_stride", ctypes.c_int32),
+        ("post_add_coff", ctypes.c_int32),
+        ("y", ctypes.c_void_p),
+        ("prec", ctypes.c_int32),
+        ("kc_max", ctypes.c_int32),
+        ("ks", ctypes.c_int32),
+    ]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_Z = ctypes.c_size_t
+_F = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/mpgan.h one to one
+PROTOTYPES = {
+    "mpg_last_error": (ctypes.c_char_p, []),
+    "mpg_version": (ctypes.c_char_p, []),
+    "mpg_device_info": (_I, [ctypes.POINTER(_I), ctypes.c_char_p, _I]),
+    "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _Z]),
+    "mpg_conv2d_fused": (_I, [_P, ctypes.POINTER(ConvDesc)]),
+    "mpg_conv2d_direct": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _F, _P]),
+    "mpg_resize_nearest": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
+    "mpg_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
+    "mpg_resize_bicubic": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
+    "mpg_avg_pool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mpg_pixel_norm": (_I, [_P, _P, _Z, _I, _F, _P]),
+    "mpg_add_act": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    "mpg_axis_zoom_linear": (_I, [_P, _P, _Z, _I, _Z, _P, _I]),
+    "mpg_volume_transpose": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P]),
+    "mpg_add_adjacent": (_I, [_P, _P, _I, _Z, _I, _I, _I, _P]),
+    "mpg_cutoff": (_I, [_P, _P, _Z, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpgError(
+            "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != MPG_OK:
+        raise MpgError("%s failed (%d): %s" % (what, rc, load().mpg_last_error().decode()))
+
+
+def device_info():
+    lib = load()
+    cu = _I(0)
+    name = ctypes.create_string_buffer(64)
+    check(lib.mpg_device_info(ctypes.byref(cu), name, 64), "mpg_device_info")
+    return cu.value, name.value.decode()

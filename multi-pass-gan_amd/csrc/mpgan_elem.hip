@@ -1,0 +1,403 @@
+// HBM-bound companions of the convolution: legacy-TF1 resampling, pooling,
+// pixel norm, the axis zoom and the volume <-> slice-batch transposes, plus a
+// plain fp32 direct convolution on the vector ALUs (strided / odd shapes and an
+// independent check of the MFMA kernel).  One thread per output element with
+// the channel (or x) index fastest, so wave accesses are contiguous.
+#include "mpgan_internal.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + BLK - 1) / BLK); }
+
+// ---------------------------------------------------------------- direct conv (tf.nn.conv2d SAME, GAN.py:686-691)
+__global__ void conv_direct_kernel(const float* __restrict__ x, int n, int h, int w, int cin,
+                                   const float* __restrict__ wt, int kh, int kw, int cout, int sh, int sw,
+                                   int oh, int ow, int pt, int pl, float wscale,
+                                   const float* __restrict__ cscale, const float* __restrict__ bias,
+                                   int act, float leak, float* __restrict__ y) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * cout;
+    if (idx >= total) return;
+    const int co = idx % cout;
+    size_t pix = idx / cout;
+    const int ox = pix % ow; pix /= ow;
+    const int oy = pix % oh;
+    const int b = pix / oh;
+    float acc = 0.f;
+    for (int dy = 0; dy < kh; ++dy) {
+        const int iy = oy * sh - pt + dy;
+        if (iy < 0 || iy >= h) continue;
+        for (int dx = 0; dx < kw; ++dx) {
+            const int ix = ox * sw - pl + dx;
+            if (ix < 0 || ix >= w) continue;
+            const float* xp = x + (((size_t)b * h + iy) * w + ix) * cin;
+            const float* wp = wt + ((size_t)(dy * kw + dx) * cin) * cout + co;
+            for (int ci = 0; ci < cin; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * cout], acc);
+        }
+    }
+    float v = acc * wscale;
+    if (cscale) v *= cscale[co];
+    if (bias) v += bias[co];
+    y[idx] = mpg::apply_act(v, act, leak);
+}
+
+// ---------------------------------------------------------------- resize (legacy TF1 coordinates)
+__global__ void resize_nearest_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                      float* __restrict__ y, int oh, int ow, float sy, float sx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const int iy = min((int)floorf(oy * sy), h - 1);
+    const int ix = min((int)floorf(ox * sx), w - 1);
+    y[idx] = x[(((size_t)b * h + iy) * w + ix) * c + ch];
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                       float* __restrict__ y, int oh, int ow, float sy, float sx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const float fy = oy * sy, fx = ox * sx;
+    const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - y0, lx = fx - x0;
+    const float* base = x + (size_t)b * h * w * c + ch;
+    const float tl = base[((size_t)y0 * w + x0) * c], tr = base[((size_t)y0 * w + x1) * c];
+    const float bl = base[((size_t)y1 * w + x0) * c], br = base[((size_t)y1 * w + x1) * c];
+    const float top = tl + (tr - tl) * lx;
+    const float bot = bl + (br - bl) * lx;
+    y[idx] = top + (bot - top) * ly;
+}
+
+// TF 1.x ResizeBicubic: Keys A = -0.75, fraction quantised to 1/1024, taps clamped.
+__device__ __forceinline__ void bicubic_taps(int o, float scale, int in_size, int idx[4], float wt[4]) {
+    const float A = -0.75f;
+    const float s = o * scale;
+    const int i = (int)floorf(s);
+    const float delta = s - (float)i;
+    const int off = (int)lrintf(delta * 1024.f);
+    const float x0 = (float)off / 1024.f;
+    const float x1 = (float)(1024 - off) / 1024.f;
+    const float xa = x0 + 1.f, xb = x1 + 1.f;
+    wt[0] = ((A * xa - 5.f * A) * xa + 8.f * A) * xa - 4.f * A;
+    wt[1] = ((A + 2.f) * x0 - (A + 3.f)) * x0 * x0 + 1.f;
+    wt[2] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    wt[3] = ((A * xb - 5.f * A) * xb + 8.f * A) * xb - 4.f * A;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) idx[t] = min(max(i - 1 + t, 0), in_size - 1);
+}
+
+__global__ void resize_bicubic_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                      float* __restrict__ y, int oh, int ow, float sy, float sx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    bicubic_taps(oy, sy, h, iy, wy);
+    bicubic_taps(ox, sx, w, ix, wx);
+    const float* base = x + (size_t)b * h * w * c + ch;
+    float out = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float row = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) row += base[((size_t)iy[r] * w + ix[t]) * c] * wx[t];
+        out += row * wy[r];
+    }
+    y[idx] = out;
+}
+
+__global__ void avg_pool2_kernel(const float* __restrict__ x, int n, int h, int w, int c, float* __restrict__ y) {
+    const int oh = h / 2, ow = w / 2;
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const float* base = x + (((size_t)b * h + 2 * oy) * w + 2 * ox) * c + ch;
+    y[idx] = (base[0] + base[c] + base[(size_t)w * c] + base[(size_t)w * c + c]) * 0.25f;
+}
+
+// one wave per pixel group: each thread owns one pixel when c is small, else strides channels
+__global__ void pixel_norm_kernel(const float* __restrict__ x, size_t npix, int c, float eps, float* __restrict__ y) {
+    const size_t pix = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (pix >= npix) return;
+    const float* p = x + pix * c;
+    float ss = 0.f;
+    for (int i = 0; i < c; ++i) ss = fmaf(p[i], p[i], ss);
+    const float sc = rsqrtf(ss / (float)c + eps);
+    float* q = y + pix * c;
+    for (int i = 0; i < c; ++i) q[i] = p[i] * sc;
+}
+
+__global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int act,
+                               float leak, float* __restrict__ y) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    float v = a[idx];
+    if (b) v += b[idx];
+    y[idx] = mpg::apply_act(v, act, leak);
+}
+
+// ---------------------------------------------------------------- volume marshalling
+__global__ void axis_zoom_kernel(const float* __restrict__ v, size_t outer, int n, size_t inner,
+                                 float* __restrict__ out, int big) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = outer * (size_t)big * inner;
+    if (idx >= total) return;
+    const size_t in = idx % inner;
+    size_t p = idx / inner;
+    const int o = p % big;
+    const size_t ou = p / big;
+    // scipy.ndimage.zoom(order=1): src = o*(n-1)/(big-1), computed in double like scipy
+    const double s = big > 1 ? (double)o * (double)(n - 1) / (double)(big - 1) : 0.0;
+    int i0 = (int)floor(s);
+    if (i0 > n - 1) i0 = n - 1;
+    const int i1 = min(i0 + 1, n - 1);
+    const double t = s - (double)i0;
+    const double a = v[(ou * n + i0) * inner + in];
+    const double b = v[(ou * n + i1) * inner + in];
+    out[idx] = (float)(a * (1.0 - t) + b * t);
+}
+
+struct PermArgs {
+    int din[3];      // input dims
+    int perm[3];     // out axis k takes input axis perm[k]
+    int cmap[8];
+    int c;
+    float cutoff;
+};
+
+// generic: one thread per output element (small, multi-channel volumes)
+__global__ void transpose_generic_kernel(const float* __restrict__ v, PermArgs a, float* __restrict__ out) {
+    const int dout[3] = {a.din[a.perm[0]], a.din[a.perm[1]], a.din[a.perm[2]]};
+    const size_t total = (size_t)dout[0] * dout[1] * dout[2] * a.c;
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % a.c;
+    size_t p = idx / a.c;
+    int o[3];
+    o[2] = p % dout[2]; p /= dout[2];
+    o[1] = p % dout[1];
+    o[0] = p / dout[1];
+    int i[3];
+    i[a.perm[0]] = o[0]; i[a.perm[1]] = o[1]; i[a.perm[2]] = o[2];
+    float val = v[(((size_t)i[0] * a.din[1] + i[1]) * a.din[2] + i[2]) * a.c + a.cmap[ch]];
+    if (a.cutoff > 0.f && val < a.cutoff) val = 0.f;
+    out[idx] = val;
+}
+
+// single-channel volumes whose innermost axis moves: 32x32 LDS tile between the input's
+// innermost axis b (=2) and the axis a that becomes innermost in the output (perm[2]); both
+// the reads and the writes are contiguous 128-byte rows.  r is the remaining axis.
+struct TileArgs {
+    int da, db, dr;
+    size_t sin_a, sin_r;            // input strides (axis b has stride 1)
+    size_t sout_b, sout_r;          // output strides (axis a has stride 1)
+    int tiles_a, tiles_b;
+    float cutoff;
+};
+
+__global__ void transpose_tiled_kernel(const float* __restrict__ v, TileArgs a, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    int bid = blockIdx.x;
+    const int tb = bid % a.tiles_b; bid /= a.tiles_b;
+    const int ta = bid % a.tiles_a;
+    const int rr = bid / a.tiles_a;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int a0 = ta * 32, b0 = tb * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ia = a0 + ty + 8 * k, ib = b0 + tx;
+        if (ia < a.da && ib < a.db) tile[ty + 8 * k][tx] = v[(size_t)rr * a.sin_r + (size_t)ia * a.sin_a + ib];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ib = b0 + ty + 8 * k, ia = a0 + tx;
+        if (ia < a.da && ib < a.db) {
+            float val = tile[tx][ty + 8 * k];
+            if (a.cutoff > 0.f && val < a.cutoff) val = 0.f;
+            out[(size_t)rr * a.sout_r + (size_t)ib * a.sout_b + ia] = val;
+        }
+    }
+}
+
+__global__ void add_adjacent_kernel(const float* __restrict__ in, int s_total, size_t hw, int c, int s_off,
+                                    int s_cnt, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)s_cnt * hw * (c + 2);
+    if (idx >= total) return;
+    const int ch = idx % (c + 2);
+    size_t p = idx / (c + 2);
+    const size_t px = p % hw;
+    const int s = (int)(p / hw) + s_off;
+    float v;
+    if (ch < c) v = in[((size_t)s * hw + px) * c + ch];
+    else if (ch == c) v = s > 0 ? in[((size_t)(s - 1) * hw + px) * c] : 0.f;
+    else v = s + 1 < s_total ? in[((size_t)(s + 1) * hw + px) * c] : 0.f;
+    out[idx] = v;
+}
+
+__global__ void cutoff_kernel(const float* __restrict__ v, size_t n, float cutoff, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    const float x = v[idx];
+    out[idx] = x < cutoff ? 0.f : x;
+}
+
+}  // namespace
+
+extern "C" int mpg_conv2d_direct(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
+                                 const float* w_hwio, int kh, int kw, int cout, int stride_h, int stride_w,
+                                 float wscale, const float* cout_scale, const float* bias, int act, float leak,
+                                 float* y) {
+    MPG_REQUIRE(x && w_hwio && y, "mpg_conv2d_direct: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_direct: bad shape");
+    MPG_REQUIRE(kh >= 1 && kw >= 1 && stride_h >= 1 && stride_w >= 1, "mpg_conv2d_direct: bad kernel/stride");
+    const int oh = (h + stride_h - 1) / stride_h, ow = (w + stride_w - 1) / stride_w;
+    int pad_h = (oh - 1) * stride_h + kh - h; if (pad_h < 0) pad_h = 0;
+    int pad_w = (ow - 1) * stride_w + kw - w; if (pad_w < 0) pad_w = 0;
+    const size_t total = (size_t)n * oh * ow * cout;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, cin,
+                       w_hwio, kh, kw, cout, stride_h, stride_w, oh, ow, pad_h / 2, pad_w / 2, wscale, cout_scale,
+                       bias, act, leak, y);
+    MPG_LAUNCH_CHECK("conv_direct_kernel");
+}
+
+#define MPG_RESIZE_ENTRY(NAME, KERNEL)                                                                        \
+    extern "C" int NAME(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y, int oh,    \
+                        int ow) {                                                                             \
+        MPG_REQUIRE(x && y, #NAME ": null pointer");                                                          \
+        MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && oh >= 1 && ow >= 1, #NAME ": bad shape");         \
+        const size_t total = (size_t)n * oh * ow * c;                                                         \
+        const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;                                     \
+        hipLaunchKernelGGL(KERNEL, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, c, y, \
+                           oh, ow, sy, sx);                                                                   \
+        MPG_LAUNCH_CHECK(#KERNEL);                                                                            \
+    }
+
+MPG_RESIZE_ENTRY(mpg_resize_nearest, resize_nearest_kernel)
+MPG_RESIZE_ENTRY(mpg_resize_bilinear, resize_bilinear_kernel)
+MPG_RESIZE_ENTRY(mpg_resize_bicubic, resize_bicubic_kernel)
+
+extern "C" int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y) {
+    MPG_REQUIRE(x && y, "mpg_avg_pool2: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 2 && w >= 2 && c >= 1, "mpg_avg_pool2: bad shape");
+    const size_t total = (size_t)n * (h / 2) * (w / 2) * c;
+    hipLaunchKernelGGL(avg_pool2_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, c, y);
+    MPG_LAUNCH_CHECK("avg_pool2_kernel");
+}
+
+extern "C" int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, int c, float eps, float* y) {
+    MPG_REQUIRE(x && y, "mpg_pixel_norm: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_pixel_norm: bad shape");
+    hipLaunchKernelGGL(pixel_norm_kernel, dim3(grid_for(npix)), dim3(BLK), 0, (hipStream_t)stream, x, npix, c, eps, y);
+    MPG_LAUNCH_CHECK("pixel_norm_kernel");
+}
+
+extern "C" int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak,
+                           float* y) {
+    MPG_REQUIRE(a && y, "mpg_add_act: null pointer");
+    if (n == 0) return MPG_OK;
+    hipLaunchKernelGGL(add_act_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, a, b, n, act, leak, y);
+    MPG_LAUNCH_CHECK("add_act_kernel");
+}
+
+extern "C" int mpg_axis_zoom_linear(mpg_stream_t stream, const float* v, size_t outer, int n, size_t inner,
+                                    float* out, int big) {
+    MPG_REQUIRE(v && out, "mpg_axis_zoom_linear: null pointer");
+    MPG_REQUIRE(outer >= 1 && n >= 1 && inner >= 1 && big >= 1, "mpg_axis_zoom_linear: bad shape");
+    const size_t total = outer * (size_t)big * inner;
+    hipLaunchKernelGGL(axis_zoom_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, v, outer, n, inner,
+                       out, big);
+    MPG_LAUNCH_CHECK("axis_zoom_kernel");
+}
+
+extern "C" int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0, int d1, int d2, int c,
+                                    const int* perm, const int* chan_map, float cutoff, float* out) {
+    MPG_REQUIRE(v && out && perm, "mpg_volume_transpose: null pointer");
+    MPG_REQUIRE(d0 >= 1 && d1 >= 1 && d2 >= 1 && c >= 1 && c <= 8, "mpg_volume_transpose: bad shape (c must be 1..8)");
+    int seen = 0;
+    for (int k = 0; k < 3; ++k) {
+        MPG_REQUIRE(perm[k] >= 0 && perm[k] < 3, "mpg_volume_transpose: perm[%d]=%d", k, perm[k]);
+        seen |= 1 << perm[k];
+    }
+    MPG_REQUIRE(seen == 7, "mpg_volume_transpose: perm is not a permutation");
+    PermArgs a;
+    a.din[0] = d0; a.din[1] = d1; a.din[2] = d2;
+    bool ident_map = true;
+    for (int k = 0; k < 3; ++k) a.perm[k] = perm[k];
+    for (int k = 0; k < 8; ++k) {
+        a.cmap[k] = (chan_map && k < c) ? chan_map[k] : k;
+        if (k < c) {
+            MPG_REQUIRE(a.cmap[k] >= 0 && a.cmap[k] < c, "mpg_volume_transpose: chan_map[%d]=%d", k, a.cmap[k]);
+            if (a.cmap[k] != k) ident_map = false;
+        }
+    }
+    a.c = c; a.cutoff = cutoff;
+    const size_t total = (size_t)d0 * d1 * d2 * c;
+    if (c == 1 && ident_map && perm[2] != 2) {
+        const int ax_a = perm[2];
+        const int ax_r = 1 - ax_a;
+        const int dout[3] = {a.din[perm[0]], a.din[perm[1]], a.din[perm[2]]};
+        size_t sin[3] = {(size_t)d1 * d2, (size_t)d2, 1};
+        size_t sout_of_in[3];   // output stride of input axis q
+        for (int k = 0; k < 3; ++k) {
+            size_t sd = 1;
+            for (int m = k + 1; m < 3; ++m) sd *= dout[m];
+            sout_of_in[perm[k]] = sd;
+        }
+        TileArgs t;
+        t.da = a.din[ax_a]; t.db = d2; t.dr = a.din[ax_r];
+        t.sin_a = sin[ax_a]; t.sin_r = sin[ax_r];
+        t.sout_b = sout_of_in[2]; t.sout_r = sout_of_in[ax_r];
+        t.tiles_a = (t.da + 31) / 32; t.tiles_b = (t.db + 31) / 32;
+        t.cutoff = cutoff;
+        const size_t nblk = (size_t)t.tiles_a * t.tiles_b * t.dr;
+        MPG_REQUIRE(nblk < (1UL << 31), "mpg_volume_transpose: grid too large");
+        hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)nblk), dim3(BLK), 0, (hipStream_t)stream, v, t, out);
+        MPG_LAUNCH_CHECK("transpose_tiled_kernel");
+    }
+    hipLaunchKernelGGL(transpose_generic_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, v, a, out);
+    MPG_LAUNCH_CHECK("transpose_generic_kernel");
+}
+
+extern "C" int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_total, size_t hw, int c, int s_off,
+                                int s_cnt, float* out) {
+    MPG_REQUIRE(in && out, "mpg_add_adjacent: null pointer");
+    MPG_REQUIRE(s_total >= 1 && hw >= 1 && c >= 1 && s_off >= 0 && s_cnt >= 1 && s_off + s_cnt <= s_total,
+                "mpg_add_adjacent: bad slice range");
+    const size_t total = (size_t)s_cnt * hw * (c + 2);
+    hipLaunchKernelGGL(add_adjacent_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, in, s_total, hw,
+                       c, s_off, s_cnt, out);
+    MPG_LAUNCH_CHECK("add_adjacent_kernel");
+}
+
+extern "C" int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out) {
+    MPG_REQUIRE(v && out, "mpg_cutoff: null pointer");
+    if (n == 0) return MPG_OK;
+    hipLaunchKernelGGL(cutoff_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, v, n, cutoff, out);
+    MPG_LAUNCH_CHECK("cutoff_kernel");
+}

@@ -1,0 +1,63 @@
+"""Slice-axis sharding over the GPUs of one node: one process per GPU,
+``torch.distributed`` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" for the
+CPU rehearsal of the partition logic).
+
+The reference is single-process / single-GPU (GAN/multipassGAN-out.py:96-97); the
+only exchange this path needs is the re-assembly of a pass's output volume
+before the next pass slices it along another axis: an all-gather of the
+per-rank slabs (S^3*4/R bytes each; 67 MB at 512^3, R = 8).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Comm(object):
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather_slabs(self, local, total):
+        """local: this rank's contiguous slab [total/world, ...] -> full [total, ...] on every rank"""
+        if self.world == 1:
+            return local
+        per = total // self.world
+        if local.shape[0] != per:
+            raise ValueError("slab has %d slices, expected %d" % (local.shape[0], per))
+        local = local.contiguous()
+        full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
+        return full
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+    def max_float(self, v, device):
+        t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+
+def init_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run; returns (comm, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world == 1:
+        return None, device
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if not dist.is_initialized():
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return Comm(), device

@@ -1,0 +1,184 @@
+"""Device-resident multi-pass volume pipeline (``generate3DUniForNewNetwork``).
+
+The reference marshals every pass through host numpy (and, in the per-network
+4x mode, through a gzip ``.uni`` file): GAN/multipassGAN-4x.py:1090-1169,
+GAN/multipassGAN-out.py:390-618.  Here the low-res volume enters HBM once and
+the final ``[z,y,x]`` volume leaves it once; the axis zoom, slice-batch
+transposes, velocity channel swaps and the cutoff are HIP kernels
+(``ops.axis_zoom_linear`` / ``volume_transpose`` / ``add_adjacent`` / ``cutoff``).
+
+Every pass shards over its slice axis: rank r of R evaluates slices
+``[r*S/R, (r+1)*S/R)`` and an all-gather reassembles the volume before the next
+pass (``dist.Comm``); with one rank this degenerates to the plain loop.
+The ``backend`` argument is the operator module (default: the HIP ``ops``).
+"""
+import torch
+
+from . import graph as G
+from . import nets, ops
+from .session import Session, VariableStore
+
+CUTOFF = 0.0005     # multipassGAN-4x.py:1156, multipassGAN-out.py:614
+
+
+class LocalComm(object):
+    """single-rank stand-in of dist.Comm"""
+    rank, world = 0, 1
+
+    def all_gather_slabs(self, local, total):
+        return local
+
+
+def slice_range(total, comm):
+    """contiguous slice range of this rank; ``total`` must divide by the world size"""
+    if total % comm.world:
+        raise ValueError("slice count %d does not divide over %d ranks" % (total, comm.world))
+    per = total // comm.world
+    return comm.rank * per, (comm.rank + 1) * per
+
+
+# ----------------------------------------------------------------------------
+# compiled generators
+# ----------------------------------------------------------------------------
+class Generator(object):
+    """One generator network: private graph + session.  Call with device tensors
+    x [N,h,w,C] (and y [N,H,W] for the later 8x generators); returns [N,H,W]."""
+
+    def __init__(self, kind, cfg, params=None, prec=ops.DEFAULT_PREC, device="cuda:0", seed=777, kc_max=0, ks=0,
+                 prec_map=None):
+        self.kind, self.cfg = kind, dict(cfg)
+        prev = G.get_default_graph()
+        self.graph = G.reset_default_graph()
+        try:
+            c = self.cfg
+            low, up, nch = c["tile_low"], c["up_res"], c["channels"]
+            self.high = low * up
+            self.y = None
+            if kind == "gen_resnet":
+                mode = c.get("upsampling_mode", 2)
+                side = low if mode == 2 else self.high
+                self.x = G.placeholder([None, side * side * nch], name="x")
+                self.sampler = nets.gen_resnet(self.x, low, up, nch, mode, use_batch_norm=c.get("batch_norm", True))
+            elif kind == "growing_gen":
+                first = c.get("first_gen", True)
+                n_in = nch + (2 if c.get("add_adj", False) else 0)
+                self.x = G.placeholder([None, low * low * n_in], name="x")
+                src = self.x
+                if not first:
+                    self.y = G.placeholder([None, None], name="y")
+                    src = nets.second_gen_input(self.x, self.y, low, self.high, nch)
+                self.sampler = nets.growing_gen(
+                    src, low, up, nch, use_batch_norm=c.get("batch_norm", False), currentUpres=nets.log2_int(up),
+                    output=True, firstGen=first, filterSize=c["filter_size"], startFms=c["start_fms"],
+                    maxFms=c["max_fms"], add_adj_idcs=c.get("add_adj", False) if first else False,
+                    first_nn_arch=c.get("first_nn_arch", False), use_res_net=c.get("use_res_net", True),
+                    pixel_norm=c.get("pixel_norm", True), upsampleMode=c.get("upsample_mode", 1),
+                    addBicubicUpsample=c.get("add_bicubic", True))
+            else:
+                raise ValueError("unknown generator kind %r" % (kind,))
+        finally:
+            G._default_graph[0] = prev
+        self.sess = Session(device=device, prec=prec, graph=self.graph,
+                            variables=VariableStore(device, seed=seed), kc_max=kc_max, ks=ks, prec_map=prec_map)
+        if params is not None:
+            self.sess.vars.load(params)
+        self.sess.vars.ensure(self.graph)
+
+    def params(self):
+        return self.sess.vars.numpy()
+
+    def __call__(self, x, y=None):
+        n = x.shape[0]
+        feeds = {self.x: x.reshape(n, -1)}
+        if self.y is not None:
+            feeds[self.y] = y.reshape(n, -1)
+        return self.sess.run_device(self.sampler, feeds).reshape(n, self.high, self.high)
+
+
+def _run_pass(gen, xs, ys, lo, hi, batch, out=None):
+    """the reference's per-pass sess.run loop (multipassGAN-out.py:443-447): slices [lo,hi) in batches"""
+    res = []
+    for j in range(lo, hi, batch):
+        k = min(j + batch, hi)
+        res.append(gen(xs[j:k], ys[j:k] if ys is not None else None))
+    return res[0] if len(res) == 1 else torch.cat(res, dim=0)
+
+
+# ----------------------------------------------------------------------------
+# 4x: two networks chained (example_run_output.py:4-8)
+# ----------------------------------------------------------------------------
+def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
+    """low: device [z,y,x,C].  Returns (final [z,y,x], pass-1 volume [z,y,x]), both with the
+    <5e-4 cutoff of the files the reference writes between and after the passes."""
+    comm = comm or LocalComm()
+    sim, nch = low.shape[0], low.shape[3]
+    s = sim * up_res
+    low1 = low
+    if nch > 1 and vel_scale != 1.0:
+        low1 = low.clone()
+        low1[..., 1:4] *= vel_scale                                  # 4x.py:283, first run: vx,vy,vz
+    # pass 1: upsamplingMode 2 -- zoom z, slices along z (4x.py:1103,1126-1133)
+    xs = backend.axis_zoom_linear(low1, 0, up_res)                   # [s, sim, sim, C]
+    lo, hi = slice_range(s, comm)
+    out1 = _run_pass(gen1, xs, None, lo, hi, batch)                  # [hi-lo, s, s] = (z, y, x)
+    out1 = backend.cutoff(out1, CUTOFF)                              # 4x.py:1156-1157
+    v1 = comm.all_gather_slabs(out1, s)                              # [z, y, x]
+    # pass 2: upsamplingMode 1 -- slices along x of (z, y) planes (4x.py:1113-1119)
+    if nch > 1:
+        vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
+        if vel_scale != 1.0:
+            vel[..., 1:3] *= vel_scale                               # 4x.py:283 on the 3-channel array: vy,vz only
+        for ax in range(3):                                          # 4x.py:1095
+            vel = backend.axis_zoom_linear(vel, ax, up_res)
+        vol = torch.cat([v1.reshape(s, s, s, 1), vel], dim=3)
+        # transpose(0,3,1,2,4) then the two channel swaps (d,vx,vy,vz) -> (d,vy,vz,vx)
+        xin = backend.volume_transpose(vol, (2, 0, 1), chan_map=[0, 2, 3, 1])
+    else:
+        xin = backend.volume_transpose(v1, (2, 0, 1)).reshape(s, s, s, 1)
+    out2 = _run_pass(gen2, xin, None, lo, hi, batch)                 # [x-range][z][y]
+    full2 = comm.all_gather_slabs(out2, s)                           # [x, z, y]
+    final = backend.volume_transpose(full2, (1, 2, 0), cutoff=CUTOFF)   # 4x.py:1142,1156
+    return final, v1
+
+
+# ----------------------------------------------------------------------------
+# 8x: up to three networks in one process (multipassGAN-out.py:390-618, transposeAxis 0)
+# ----------------------------------------------------------------------------
+def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops, apply_cutoff=True):
+    """gens: 1..3 Generator objects (first one firstGen).  low: device [z,y,x,4] with velocities
+    already scaled by velScale (out.py:138).  Returns the [z,y,x] density volume."""
+    comm = comm or LocalComm()
+    sim, nch = low.shape[0], low.shape[3]
+    s = sim * up_res
+    lo, hi = slice_range(s, comm)
+    # pass 1 (397-461): zoom z, slices along z, add_adj_idcs channels
+    xs = backend.axis_zoom_linear(low, 0, up_res)
+    if gens[0].cfg.get("add_adj", False):
+        xs_r = backend.add_adjacent(xs, lo, hi - lo)
+        out = _run_pass(gens[0], xs_r, None, 0, hi - lo, batches[0])
+    else:
+        out = _run_pass(gens[0], xs, None, lo, hi, batches[0])
+    vol = comm.all_gather_slabs(out, s)                                  # (z, y, x)
+    order = "zyx"
+    if len(gens) > 1:
+        # pass 2 (463-523): planes (y,z) along x.  dim_output.transpose(2,1,0) (:459)
+        ys = backend.volume_transpose(vol, (2, 1, 0))                    # (x, y, z)
+        xl = backend.axis_zoom_linear(low, 2, up_res)                    # [z, y, S, C]
+        xl = backend.volume_transpose(xl, (2, 1, 0), chan_map=[0, 3, 2, 1])   # :472-475
+        out = _run_pass(gens[1], xl, ys, lo, hi, batches[1])
+        vol = comm.all_gather_slabs(out, s)                              # (x, y, z)
+        order = "xyz"
+    if len(gens) > 2:
+        # pass 3 (525-585): planes (z,x) along y.  previous result .transpose(1,2,0) (:521) -> (y,z,x)
+        ys = backend.volume_transpose(vol, (1, 2, 0))                    # (y, z, x)
+        xl = backend.axis_zoom_linear(low, 1, up_res)                    # [z, S, x, C]
+        xl = backend.volume_transpose(xl, (1, 0, 2), chan_map=[0, 1, 3, 2])   # :528-531
+        out = _run_pass(gens[2], xl, ys, lo, hi, batches[2])
+        vol = comm.all_gather_slabs(out, s)                              # (y, z, x)
+        order = "yzx"
+    # final axis restore (587-590) and cutoff (614-615)
+    thr = CUTOFF if apply_cutoff else 0.0
+    perm = {"zyx": (0, 1, 2), "xyz": (2, 1, 0), "yzx": (1, 0, 2)}[order]
+    if perm == (0, 1, 2):
+        return backend.cutoff(vol, CUTOFF) if apply_cutoff else vol
+    return backend.volume_transpose(vol, perm, cutoff=thr)

@@ -1,0 +1,276 @@
+"""Operator layer: thin, checked wrappers of the C ABI on PyTorch-ROCm tensors.
+
+PyTorch is used for device memory and streams only; every function here
+enqueues hand-written HIP kernels from libmpgan_hip.so on torch's current
+stream.  Tensors are NHWC float32 on the GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
+
+DEFAULT_PREC = PREC_F16X3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name="tensor", dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.MpgError("%s must be a GPU tensor (the HIP path has no CPU fallback)" % name)
+    if t.dtype != dtype:
+        raise _lib.MpgError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.MpgError("%s must be contiguous" % name)
+    return t
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class PackedWeights(object):
+    """Weights of one conv segment in MFMA fragment order (mpg_conv_pack_weights)."""
+
+    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec", "kc_max", "ks")
+
+    def __init__(self, buf, kh, kw, cin, cout, prec, kc_max, ks):
+        self.buf, self.kh, self.kw, self.cin, self.cout = buf, kh, kw, cin, cout
+        self.prec, self.kc_max, self.ks = prec, kc_max, ks
+
+
+def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, prec=DEFAULT_PREC, kc_max=0, ks=0):
+    """Pack W[kh,kw,cin_total,cout] channels [c_off, c_off+cin) times wscale
+    (GAN.weight_variable, GAN.py:664-668) times an optional per-channel scale
+    (folded batch norm, GAN.py:110)."""
+    lib = _lib.load()
+    w = _dev(w_hwio, "w_hwio")
+    kh, kw, cin_total, cout = w.shape
+    cin = cin_total - c_off if cin is None else cin
+    nbytes = lib.mpg_conv_pack_size(kh, kw, cin, cout, prec, kc_max, ks)
+    if nbytes == 0:
+        raise _lib.MpgError("mpg_conv_pack_size: unsupported conv %dx%d %d->%d" % (kh, kw, cin, cout))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    cs = _dev(cout_scale, "cout_scale") if cout_scale is not None else None
+    rc = lib.mpg_conv_pack_weights(_stream(), _ptr(w), kh, kw, cin_total, c_off, cin, cout, float(wscale), _ptr(cs),
+                                   prec, kc_max, ks, _ptr(buf), nbytes)
+    _lib.check(rc, "mpg_conv_pack_weights")
+    return PackedWeights(buf, kh, kw, cin, cout, prec, kc_max, ks)
+
+
+class Segment(object):
+    """One K-slice of a fused convolution: source tensor, channel window, packed weights."""
+
+    __slots__ = ("x", "packed", "c_off", "up_log2")
+
+    def __init__(self, x, packed, c_off=0, up_log2=0):
+        self.x, self.packed, self.c_off, self.up_log2 = x, packed, c_off, up_log2
+
+
+def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=False, pn_eps=1e-8,
+                 post_add=None, post_add_coff=0, out=None):
+    """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h."""
+    lib = _lib.load()
+    if not 1 <= len(segments) <= _lib.MAX_SEG:
+        raise _lib.MpgError("conv2d_fused: %d segments (1..%d supported)" % (len(segments), _lib.MAX_SEG))
+    p0 = segments[0].packed
+    h, w = out_hw
+    n = segments[0].x.shape[0]
+    d = _lib.ConvDesc()
+    d.n, d.h, d.w, d.cout, d.nseg = n, h, w, p0.cout, len(segments)
+    for i, s in enumerate(segments):
+        x = _dev(s.x, "segment %d input" % i)
+        pk = s.packed
+        if (pk.cout, pk.prec, pk.kc_max, pk.ks) != (p0.cout, p0.prec, p0.kc_max, p0.ks):
+            raise _lib.MpgError("conv2d_fused: segments packed with different cout/prec/tuning")
+        if x.dim() != 4 or x.shape[0] != n or x.shape[1] << s.up_log2 != h or x.shape[2] << s.up_log2 != w:
+            raise _lib.MpgError("conv2d_fused: segment %d input %s does not match output %dx%dx%d (up 2^%d)"
+                                % (i, tuple(x.shape), n, h, w, s.up_log2))
+        if s.c_off + pk.cin > x.shape[3]:
+            raise _lib.MpgError("conv2d_fused: segment %d channel window [%d,%d) exceeds %d"
+                                % (i, s.c_off, s.c_off + pk.cin, x.shape[3]))
+        g = d.seg[i]
+        g.x, g.wpack = x.data_ptr(), pk.buf.data_ptr()
+        g.cin, g.cin_stride, g.c_off = pk.cin, x.shape[3], s.c_off
+        g.kh, g.kw, g.up_log2 = pk.kh, pk.kw, s.up_log2
+    if bias is not None:
+        b = _dev(bias, "bias")
+        if b.numel() != p0.cout:
+            raise _lib.MpgError("conv2d_fused: bias has %d entries, cout is %d" % (b.numel(), p0.cout))
+        d.bias = b.data_ptr()
+    d.act, d.leak = _lib.act_id(act), leak
+    d.pixel_norm, d.pn_eps = int(bool(pixel_norm)), pn_eps
+    if post_add is not None:
+        pa = _dev(post_add, "post_add")
+        if pa.dim() != 4 or tuple(pa.shape[:3]) != (n, h, w) or post_add_coff + p0.cout > pa.shape[3]:
+            raise _lib.MpgError("conv2d_fused: post_add %s does not match output" % (tuple(pa.shape),))
+        d.post_add, d.post_add_stride, d.post_add_coff = pa.data_ptr(), pa.shape[3], post_add_coff
+    if out is None:
+        out = torch.empty((n, h, w, p0.cout), dtype=torch.float32, device=segments[0].x.device)
+    else:
+        _dev(out, "out")
+        if tuple(out.shape) != (n, h, w, p0.cout):
+            raise _lib.MpgError("conv2d_fused: out has shape %s" % (tuple(out.shape),))
+    d.y = out.data_ptr()
+    d.prec, d.kc_max, d.ks = p0.prec, p0.kc_max, p0.ks
+    _lib.check(lib.mpg_conv2d_fused(_stream(), ctypes.byref(d)), "mpg_conv2d_fused")
+    return out
+
+
+def conv2d_direct(x, w_hwio, stride=(1, 1), wscale=1.0, cout_scale=None, bias=None, act=None, leak=0.2):
+    """fp32 vector-ALU convolution, any stride (tf.nn.conv2d SAME, GAN.py:686-691)."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    w = _dev(w_hwio, "w_hwio")
+    n, h, wd, cin = x.shape
+    kh, kw, cin2, cout = w.shape
+    if cin != cin2:
+        raise _lib.MpgError("conv2d_direct: input has %d channels, weights expect %d" % (cin, cin2))
+    sh, sw = stride
+    oh, ow = -(-h // sh), -(-wd // sw)
+    y = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=x.device)
+    cs = _dev(cout_scale, "cout_scale") if cout_scale is not None else None
+    b = _dev(bias, "bias") if bias is not None else None
+    rc = lib.mpg_conv2d_direct(_stream(), _ptr(x), n, h, wd, cin, _ptr(w), kh, kw, cout, sh, sw, float(wscale),
+                               _ptr(cs), _ptr(b), _lib.act_id(act), leak, _ptr(y))
+    _lib.check(rc, "mpg_conv2d_direct")
+    return y
+
+
+def _resize(fn_name, x, oh, ow):
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    _lib.check(getattr(lib, fn_name)(_stream(), _ptr(x), n, h, w, c, _ptr(y), oh, ow), fn_name)
+    return y
+
+
+def resize_nearest(x, oh, ow):
+    return _resize("mpg_resize_nearest", x, oh, ow)
+
+
+def resize_bilinear(x, oh, ow):
+    return _resize("mpg_resize_bilinear", x, oh, ow)
+
+
+def resize_bicubic(x, oh, ow):
+    return _resize("mpg_resize_bicubic", x, oh, ow)
+
+
+def resize_images(x, oh, ow, method):
+    """tf.image.resize_images method ids (GAN.py:541): 0 bilinear, 1 nearest, 2 bicubic."""
+    if method == 0:
+        return resize_bilinear(x, oh, ow)
+    if method == 1:
+        return resize_nearest(x, oh, ow)
+    if method == 2:
+        return resize_bicubic(x, oh, ow)
+    raise _lib.MpgError("resize method %r not supported" % (method,))
+
+
+def avg_pool2(x):
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_avg_pool2(_stream(), _ptr(x), n, h, w, c, _ptr(y)), "mpg_avg_pool2")
+    return y
+
+
+def pixel_norm(x, eps=1e-8):
+    lib = _lib.load()
+    x = _dev(x, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    _lib.check(lib.mpg_pixel_norm(_stream(), _ptr(x), x.numel() // c, c, eps, _ptr(y)), "mpg_pixel_norm")
+    return y
+
+
+def add_act(a, b=None, act=None, leak=0.2):
+    lib = _lib.load()
+    a = _dev(a, "a")
+    if b is not None:
+        b = _dev(b, "b")
+        if b.shape != a.shape:
+            raise _lib.MpgError("add_act: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    y = torch.empty_like(a)
+    _lib.check(lib.mpg_add_act(_stream(), _ptr(a), _ptr(b), a.numel(), _lib.act_id(act), leak, _ptr(y)), "mpg_add_act")
+    return y
+
+
+def axis_zoom_linear(v, axis, factor):
+    """scipy.ndimage.zoom(v, factor on `axis`, order=1) (multipassGAN-out.py:421)."""
+    lib = _lib.load()
+    v = _dev(v, "v")
+    n = v.shape[axis]
+    big = int(round(n * factor))
+    outer = 1
+    for d in v.shape[:axis]:
+        outer *= d
+    inner = 1
+    for d in v.shape[axis + 1:]:
+        inner *= d
+    shape = list(v.shape)
+    shape[axis] = big
+    out = torch.empty(shape, dtype=torch.float32, device=v.device)
+    if v.numel() == 0:
+        return out
+    _lib.check(lib.mpg_axis_zoom_linear(_stream(), _ptr(v), outer, n, inner, _ptr(out), big), "mpg_axis_zoom_linear")
+    return out
+
+
+def volume_transpose(v, perm, chan_map=None, cutoff=0.0):
+    """numpy.transpose of [d0,d1,d2(,c)] by `perm` (3 axes) with optional channel
+    permutation and cutoff (multipassGAN-out.py:459,472-475,614)."""
+    lib = _lib.load()
+    v = _dev(v, "v")
+    if v.dim() == 3:
+        d0, d1, d2 = v.shape
+        c = 1
+        squeeze = True
+    elif v.dim() == 4:
+        d0, d1, d2, c = v.shape
+        squeeze = False
+    else:
+        raise _lib.MpgError("volume_transpose: expected a 3D or 4D tensor, got %s" % (tuple(v.shape),))
+    perm = [int(p) for p in perm]
+    if sorted(perm) != [0, 1, 2]:
+        raise _lib.MpgError("volume_transpose: perm %r is not a permutation of (0,1,2)" % (perm,))
+    dims = (d0, d1, d2)
+    oshape = [dims[perm[0]], dims[perm[1]], dims[perm[2]]] + ([] if squeeze else [c])
+    out = torch.empty(oshape, dtype=torch.float32, device=v.device)
+    if v.numel() == 0:
+        return out
+    p_arr = (ctypes.c_int * 3)(*perm)
+    cm = None
+    if chan_map is not None:
+        if len(chan_map) != c:
+            raise _lib.MpgError("volume_transpose: chan_map has %d entries for %d channels" % (len(chan_map), c))
+        cm = (ctypes.c_int * c)(*[int(k) for k in chan_map])
+    rc = lib.mpg_volume_transpose(_stream(), _ptr(v), d0, d1, d2, c, p_arr, cm, float(cutoff), _ptr(out))
+    _lib.check(rc, "mpg_volume_transpose")
+    return out
+
+
+def add_adjacent(x, s_off=0, s_cnt=None):
+    """add_adj_idcs channels for slices [s_off, s_off+s_cnt) of x [S,H,W,C] (multipassGAN-out.py:423-436)."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    s, h, w, c = x.shape
+    s_cnt = s - s_off if s_cnt is None else s_cnt
+    out = torch.empty((s_cnt, h, w, c + 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_add_adjacent(_stream(), _ptr(x), s, h * w, c, s_off, s_cnt, _ptr(out)), "mpg_add_adjacent")
+    return out
+
+
+def cutoff(v, thr=0.0005, out=None):
+    """v[v < thr] = 0 (multipassGAN-4x.py:1156-1157)."""
+    lib = _lib.load()
+    v = _dev(v, "v")
+    out = torch.empty_like(v) if out is None else out
+    _lib.check(lib.mpg_cutoff(_stream(), _ptr(v), v.numel(), thr, _ptr(out)), "mpg_cutoff")
+    return out

@@ -1,0 +1,479 @@
+"""Executes ``graph`` nodes as fused HIP launches (the ``sess.run`` of the reference).
+
+Fusion rules (all arithmetic stays in the kernels of libmpgan_hip.so):
+  * conv2d -> bias_add -> [batch_norm(inference)] -> [activation] -> [pixel_norm]
+    is one ``mpg_conv2d_fused`` launch; batch norm is folded into the packed
+    weights and the bias (GAN.py:108-113);
+  * ``add`` of two such linear chains (the residual shortcut of resBlock,
+    multipassGAN-4x.py:523) becomes one launch with two K-segments;
+  * a conv reading ``concat`` / nearest ``resize`` / channel ``slice`` nodes reads
+    their sources directly (multipassGAN-out.py:357; GAN.py:517);
+  * ``chain + tensor`` with a linear chain on one side is the epilogue post-add
+    (addBicubicUpsample, multipassGAN-out.py:327-332).
+Everything else falls back to one kernel per node.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from . import graph as G
+
+
+class VariableStore(object):
+    """Device-resident parameters keyed by TF variable path (GAN.py:668,683)."""
+
+    def __init__(self, device="cuda:0", seed=777, bn_seed=4321):
+        self.device = torch.device(device)
+        self.values = {}
+        self.version = 0
+        self.seed, self.bn_seed = seed, bn_seed
+
+    @staticmethod
+    def synthetic(name, shape, kind, seed=777, bn_seed=4321):
+        """Synthetic init: weight ~ N(0,1) (GAN.py:668), bias 0.1 (GAN.py:683),
+        batch-norm statistics perturbed so BN is not the identity.  Name-keyed streams."""
+        h = 0
+        for ch in name:
+            h = (h * 131 + ord(ch)) % (2 ** 31 - 1)
+        if kind == "weight":
+            return np.random.default_rng([seed, h]).standard_normal(shape).astype(np.float32)
+        if kind == "bias":
+            return np.full(shape, 0.1, dtype=np.float32)
+        rng = np.random.default_rng([bn_seed, h])
+        if kind == "gamma":
+            return (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        if kind in ("beta", "moving_mean"):
+            return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+        if kind == "moving_variance":
+            return (1.0 + 0.2 * rng.random(shape)).astype(np.float32)
+        raise G.GraphError("unknown variable kind %r" % (kind,))
+
+    def ensure(self, graph):
+        for name, spec in graph.variables.items():
+            if name not in self.values:
+                self.set(name, self.synthetic(name, spec.shape, spec.kind, self.seed, self.bn_seed))
+            elif tuple(self.values[name].shape) != spec.shape:
+                raise G.GraphError("variable %s has shape %s, graph expects %s"
+                                   % (name, tuple(self.values[name].shape), spec.shape))
+
+    def set(self, name, value):
+        self.values[name] = torch.as_tensor(np.ascontiguousarray(value), dtype=torch.float32).to(self.device)
+        self.version += 1
+
+    def load(self, params, prefix=""):
+        for k, v in params.items():
+            self.set(prefix + k, v)
+
+    def numpy(self):
+        return {k: v.cpu().numpy() for k, v in self.values.items()}
+
+    def get(self, name):
+        return self.values[name]
+
+
+class _Term(object):
+    """bn(bias_add(conv2d(src, W))) -- one linear term of a fused convolution."""
+
+    __slots__ = ("conv", "bias", "bn")
+
+    def __init__(self, conv, bias=None, bn=None):
+        self.conv, self.bias, self.bn = conv, bias, bn
+
+
+def _is_pow2(v):
+    return v >= 1 and (v & (v - 1)) == 0
+
+
+class _Plan(object):
+    def __init__(self):
+        self.steps = []       # (node, callable(env) -> tensor)
+        self.last_use = {}    # node id -> index of the last step reading it
+        self.free_after = []  # per step: node ids whose tensors are dead afterwards
+
+
+class Session(object):
+    def __init__(self, device="cuda:0", prec=ops.DEFAULT_PREC, variables=None, graph=None, kc_max=0, ks=0,
+                 prec_map=None):
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MpgError("no GPU visible: the multi-pass GAN path has no CPU fallback")
+        self.device = torch.device(device)
+        self.prec, self.kc_max, self.ks = prec, kc_max, ks
+        # per-launch precision override: [(substring of the first term's weight name, prec), ...]
+        self.prec_map = list(prec_map or [])
+        self.graph = graph or G.get_default_graph()
+        self.vars = variables or VariableStore(device)
+        self._plans = {}
+        self._packed = {}
+        self._folded = {}
+        self._cache_version = -1
+
+    # ------------------------------------------------------------------ public
+    def run(self, fetches, feed_dict=None):
+        """numpy in / numpy out, like ``sess.run(sampler, feed_dict={x: ...})``."""
+        single = isinstance(fetches, G.Node)
+        flist = [fetches] if single else list(fetches)
+        feeds = {}
+        for k, v in (feed_dict or {}).items():
+            if isinstance(k, G.Node):
+                feeds[k] = torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(self.device)
+        outs = [self.run_device(f, feeds).cpu().numpy() for f in flist]
+        return outs[0] if single else outs
+
+    def run_device(self, fetch, feeds):
+        """device tensors in / device tensor out (what the multi-pass pipeline uses)."""
+        self.vars.ensure(self.graph)
+        if self._cache_version != self.vars.version:
+            self._packed.clear()
+            self._folded.clear()
+            self._cache_version = self.vars.version
+        plan = self._plans.get(fetch.id)
+        if plan is None:
+            plan = self._compile(fetch)
+            self._plans[fetch.id] = plan
+        env = {}
+        for node, t in feeds.items():
+            env[node.id] = t
+        for i, (node, fn) in enumerate(plan.steps):
+            env[node.id] = fn(env)
+            for nid in plan.free_after[i]:
+                env.pop(nid, None)
+        return env[fetch.id]
+
+    # ------------------------------------------------------------------ compile
+    def _compile(self, fetch):
+        consumers = {}
+        order = []
+        seen = set()
+
+        def visit(n):
+            if n.id in seen:
+                return
+            seen.add(n.id)
+            for i in n.inputs:
+                consumers.setdefault(i.id, []).append(n)
+                visit(i)
+            order.append(n)
+
+        visit(fetch)
+        self._consumers = consumers
+        self._fetch = fetch
+        plan = _Plan()
+        done = set()
+
+        def single_use(n):
+            return len(consumers.get(n.id, [])) == 1 and n is not fetch
+
+        def emit(n):
+            if n.id in done:
+                return
+            done.add(n.id)
+            if n.op == "variable":
+                plan.steps.append((n, lambda env, nm=n.attrs["var"]: self.vars.get(nm)))
+                return
+            if n.op == "placeholder":
+                def feed(env, node=n):
+                    if node.id not in env:
+                        raise G.GraphError("placeholder %s was not fed" % node.name)
+                    return env[node.id]
+                plan.steps.append((n, feed))
+                return
+            fused = self._match_fused(n, single_use)
+            if fused is not None:
+                deps, fn = fused
+            else:
+                deps, fn = self._fallback(n, single_use)
+            for d in deps:
+                emit(d)
+            idx = len(plan.steps)
+            plan.steps.append((n, fn))
+            for d in deps:
+                plan.last_use[d.id] = idx
+
+        emit(fetch)
+        # variables, placeholders and the fetch stay alive; everything else dies after its last reader
+        plan.free_after = [[] for _ in plan.steps]
+        keep = set(n.id for n, _ in plan.steps if n.op in ("variable", "placeholder"))
+        keep.add(fetch.id)
+        for nid, idx in plan.last_use.items():
+            if nid not in keep:
+                plan.free_after[idx].append(nid)
+        return plan
+
+    # ---- pattern matching -------------------------------------------------
+    def _match_term(self, n, single_use):
+        """bn?(bias_add?(conv2d)) with stride 1, cout <= 128, k <= 7.  The root n may have any
+        number of consumers (the caller decides); every inner node must feed this chain only."""
+        bn = bias = None
+        cur = n
+        if cur.op == "batch_norm":
+            if cur.attrs["training"]:
+                return None
+            bn = cur
+            cur = cur.inputs[0]
+            if not single_use(cur):
+                return None
+        if cur.op == "bias_add":
+            bias = cur
+            cur = cur.inputs[0]
+            if not single_use(cur):
+                return None
+        if cur.op != "conv2d" or cur.attrs["stride"] != (1, 1):
+            return None
+        kh, kw, cin, cout = cur.inputs[1].shape
+        if cout > 128 or kh > 7 or kw > 7 or cur.inputs[1].op != "variable":
+            return None
+        return _Term(cur, bias, bn)
+
+    def _match_lin(self, n, single_use, top=True):
+        if n.op == "add":
+            if not top and not single_use(n):
+                return None
+            a = self._match_lin(n.inputs[0], single_use, False) if single_use(n.inputs[0]) else None
+            b = self._match_lin(n.inputs[1], single_use, False) if single_use(n.inputs[1]) else None
+            if a is not None and b is not None:
+                return a + b
+            return None
+        t = self._match_term(n, single_use)
+        return [t] if t is not None else None
+
+    def _match_fused(self, n, single_use):
+        post_add = None
+        cur = n
+        # chain + tensor  (only valid as the last op: the epilogue adds after act / pixel norm)
+        if cur.op == "add" and self._match_lin(cur, single_use) is None:
+            for side in (0, 1):
+                cand, other = cur.inputs[side], cur.inputs[1 - side]
+                if single_use(cand) and self._match_chain(cand, single_use) is not None:
+                    post_add = other
+                    cur = cand
+                    break
+            if post_add is None:
+                return None
+        chain = self._match_chain(cur, single_use, top=(post_add is None))
+        if chain is None:
+            return None
+        terms, act, leak, pn, pn_eps = chain
+        cout = terms[0].conv.shape[3]
+        if any(t.conv.shape[3] != cout for t in terms):
+            return None
+        segs = []
+        for t in terms:
+            s = self._segments_of(t)
+            if s is None:
+                return None
+            segs.extend(s)
+        if len(segs) > _lib.MAX_SEG:
+            return None
+        deps = [s[0] for s in segs] + ([post_add] if post_add is not None else [])
+        out_hw = (n.shape[1], n.shape[2])
+
+        lead = terms[0].conv.inputs[1].attrs["var"]
+        prec = self.prec
+        for pat, pr in self.prec_map:
+            if pat in lead:
+                prec = pr
+
+        def run(env, segs=segs, terms=terms, prec=prec):
+            seg_objs = []
+            for (src, c_off_src, up, term, w_off, cin) in segs:
+                pk = self._packed_for(term, w_off, cin, prec)
+                seg_objs.append(ops.Segment(env[src.id], pk, c_off_src, up))
+            bias = self._bias_for(terms)
+            pa = env[post_add.id] if post_add is not None else None
+            return ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
+                                    post_add=pa)
+
+        return deps, run
+
+    def _match_chain(self, n, single_use, top=True):
+        """[pixel_norm]([act](lin)) -> (terms, act, leak, pn, eps)."""
+        cur = n
+        pn, pn_eps, act, leak = False, 1e-8, None, 0.2
+        first = True
+
+        def ok(node):
+            return (first and top) or single_use(node)
+
+        if cur.op == "pixel_norm" and ok(cur):
+            pn, pn_eps = True, cur.attrs["eps"]
+            cur = cur.inputs[0]
+            first = False
+        if cur.op == "act" and ok(cur):
+            act, leak = cur.attrs["act"], cur.attrs.get("leak", 0.2)
+            cur = cur.inputs[0]
+            first = False
+        if not ok(cur):
+            return None
+        terms = self._match_lin(cur, single_use, top=True)
+        if terms is None:
+            return None
+        return terms, act, leak, pn, pn_eps
+
+    def _segments_of(self, term):
+        """Resolve the conv input into (source node, channel offset in source, up_log2, term,
+        weight channel offset, channel count) tuples, looking through concat / nearest resize / slice."""
+        out_h, out_w = term.conv.shape[1], term.conv.shape[2]
+        out = []
+
+        def resolve(node, c_lo, c_hi, w_off, up):
+            # channels [c_lo, c_hi) of `node` feed weight channels starting at w_off
+            if node.op == "concat":
+                base = 0
+                for part in node.inputs:
+                    pc = part.shape[3]
+                    lo, hi = max(c_lo, base), min(c_hi, base + pc)
+                    if lo < hi:
+                        if not resolve(part, lo - base, hi - base, w_off + (lo - c_lo), up):
+                            return False
+                    base += pc
+                return True
+            if node.op == "slice":
+                b = node.attrs["begin"]
+                return resolve(node.inputs[0], c_lo + b, c_hi + b, w_off, up)
+            if node.op == "resize" and node.attrs["method"] == 1 and up == 0:
+                src = node.inputs[0]
+                fy, fx = node.attrs["oh"] // src.shape[1], node.attrs["ow"] // src.shape[2]
+                if (fy == fx and _is_pow2(fy) and fy <= 16 and src.shape[1] * fy == node.attrs["oh"]
+                        and src.shape[2] * fx == node.attrs["ow"]):
+                    return resolve(src, c_lo, c_hi, w_off, fy.bit_length() - 1)
+            if node.op == "reshape" and len(node.shape) == 4 and node.inputs[0].shape is not None \
+                    and len(node.inputs[0].shape) == 4 and tuple(node.inputs[0].shape[1:]) == tuple(node.shape[1:]):
+                return resolve(node.inputs[0], c_lo, c_hi, w_off, up)
+            if len(node.shape) != 4 or (node.shape[1] << up) != out_h or (node.shape[2] << up) != out_w:
+                return False
+            out.append((node, c_lo, up, term, w_off, c_hi - c_lo))
+            return True
+
+        src = term.conv.inputs[0]
+        if not resolve(src, 0, src.shape[3], 0, 0):
+            return None
+        return out
+
+    # ---- parameter folding / packing ----------------------------------------
+    def _bn_scale_shift(self, term):
+        """(scale, shift) with y = scale * (conv + bias) + shift folded: returns per-channel
+        scale s = gamma / sqrt(var + eps) and the effective bias s*(b - mean) + beta."""
+        key = ("fold", term.conv.id)
+        if key in self._folded:
+            return self._folded[key]
+        cout = term.conv.shape[3]
+        b = self.vars.get(term.bias.inputs[1].attrs["var"]).double() if term.bias is not None else \
+            torch.zeros(cout, dtype=torch.float64, device=self.device)
+        if term.bn is not None:
+            gamma, beta, mean, var = [self.vars.get(v.attrs["var"]).double() for v in term.bn.inputs[1:5]]
+            s = gamma / torch.sqrt(var + term.bn.attrs["eps"])
+            eff = s * (b - mean) + beta
+            res = (s.float().contiguous(), eff)
+        else:
+            res = (None, b)
+        self._folded[key] = res
+        return res
+
+    def _packed_for(self, term, w_off, cin, prec):
+        key = ("pack", term.conv.id, w_off, cin, prec, self.kc_max, self.ks)
+        pk = self._packed.get(key)
+        if pk is None:
+            w = self.vars.get(term.conv.inputs[1].attrs["var"])
+            scale, _ = self._bn_scale_shift(term)
+            pk = ops.pack_conv_weights(w, wscale=term.conv.attrs["wscale"], cout_scale=scale, c_off=w_off, cin=cin,
+                                       prec=prec, kc_max=self.kc_max, ks=self.ks)
+            self._packed[key] = pk
+        return pk
+
+    def _bias_for(self, terms):
+        key = ("bias",) + tuple(t.conv.id for t in terms)
+        b = self._folded.get(key)
+        if b is None:
+            tot = None
+            for t in terms:
+                _, eff = self._bn_scale_shift(t)
+                tot = eff if tot is None else tot + eff
+            b = tot.float().contiguous()
+            self._folded[key] = b
+        return b
+
+    # ---- one kernel per node ----------------------------------------------------
+    def _fallback(self, n, single_use):
+        op = n.op
+        if op == "reshape":
+            tgt = n.attrs["target"]
+            return [n.inputs[0]], lambda env, i=n.inputs[0], t=tgt: env[i.id].reshape(t)
+        if op == "concat":
+            return list(n.inputs), lambda env, ins=n.inputs: torch.cat([env[i.id] for i in ins], dim=-1).contiguous()
+        if op == "slice":
+            b, s = n.attrs["begin"], n.attrs["size"]
+            return [n.inputs[0]], lambda env, i=n.inputs[0]: env[i.id][..., b:b + s].contiguous()
+        if op == "slice_flat":
+            cnt = n.attrs["count"]
+            return [n.inputs[0]], lambda env, i=n.inputs[0]: env[i.id].reshape(env[i.id].shape[0], -1)[:, :cnt].contiguous()
+        if op == "add":
+            a, b = n.inputs
+            return [a, b], lambda env: ops.add_act(env[a.id], env[b.id])
+        if op == "act":
+            x = n.inputs[0]
+            if x.op == "add" and single_use(x):
+                a, b = x.inputs
+                return [a, b], lambda env: ops.add_act(env[a.id], env[b.id], n.attrs["act"], n.attrs.get("leak", 0.2))
+            direct = self._match_direct(n, single_use)
+            if direct is not None:
+                return direct
+            return [x], lambda env: ops.add_act(env[x.id], None, n.attrs["act"], n.attrs.get("leak", 0.2))
+        if op == "pixel_norm":
+            x = n.inputs[0]
+            return [x], lambda env: ops.pixel_norm(env[x.id], n.attrs["eps"])
+        if op == "resize":
+            x = n.inputs[0]
+            return [x], lambda env: ops.resize_images(env[x.id], n.attrs["oh"], n.attrs["ow"], n.attrs["method"])
+        if op == "avg_pool":
+            x = n.inputs[0]
+            return [x], lambda env: ops.avg_pool2(env[x.id])
+        if op in ("conv2d", "bias_add", "batch_norm"):
+            direct = self._match_direct(n, single_use)
+            if direct is not None:
+                return direct
+        raise G.GraphError("no HIP lowering for node %r (inputs %r)" % (n, n.inputs))
+
+    def _match_direct(self, n, single_use):
+        """[act](bn?(bias_add?(conv2d | matmul))) on the vector-ALU kernel: strided convs, cout > 128, FC."""
+        cur = n
+        act, leak = None, 0.2
+        if cur.op == "act":
+            act, leak = cur.attrs["act"], cur.attrs.get("leak", 0.2)
+            nxt = cur.inputs[0]
+            if not single_use(nxt):
+                return None
+            cur = nxt
+        bn = bias = None
+        if cur.op == "batch_norm":
+            if cur.attrs["training"]:
+                raise NotImplementedError("training-mode batch norm is not lowered yet")
+            bn = cur
+            if not single_use(cur.inputs[0]):
+                return None
+            cur = cur.inputs[0]
+        if cur.op == "bias_add":
+            bias = cur
+            if not single_use(cur.inputs[0]):
+                return None
+            cur = cur.inputs[0]
+        if cur.op not in ("conv2d", "matmul"):
+            return None
+        conv = cur
+        x, wv = conv.inputs
+        term = _Term(conv, bias, bn)
+        is_fc = conv.op == "matmul"
+
+        def run(env):
+            scale, eff = self._bn_scale_shift(term)
+            b = eff.float().contiguous()
+            w = self.vars.get(wv.attrs["var"])
+            xin = env[x.id]
+            if is_fc:
+                y = ops.conv2d_direct(xin.reshape(xin.shape[0], 1, 1, xin.shape[1]).contiguous(),
+                                      w.reshape(1, 1, w.shape[0], w.shape[1]), (1, 1), conv.attrs["wscale"], scale, b,
+                                      act, leak)
+                return y.reshape(xin.shape[0], w.shape[1])
+            return ops.conv2d_direct(xin, w, conv.attrs["stride"], conv.attrs["wscale"], scale, b, act, leak)
+
+        return [x], run

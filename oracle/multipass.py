@@ -86,11 +86,12 @@ def pass2_4x(ps, x2, low, up_res=4, batch_norm=True, vel_scale=1.0):
 def two_pass_4x(ps1, ps2, low, up_res=4, batch_norm=True, vel_scale=1.0):
     """C1/C2 of BASELINE.json: the two ``multipassGAN-4x.py out 1`` runs of
     example_run_output.py:4-8 chained through the intermediate volume."""
-    low = np.array(low, dtype=F32, copy=True)
+    low = np.asarray(low, dtype=F32)
+    low1 = np.array(low, copy=True)
     if low.shape[-1] > 1:
-        low[..., 1:4] = F32(vel_scale) * low[..., 1:4]            # :283, run 1
-    v1 = pass1_4x(ps1, low, up_res, batch_norm)
-    v2 = pass2_4x(ps2, v1, low, up_res, batch_norm, 1.0)
+        low1[..., 1:4] = F32(vel_scale) * low1[..., 1:4]          # :283, run 1 (x_3d = x: all of vx,vy,vz)
+    v1 = pass1_4x(ps1, low1, up_res, batch_norm)
+    v2 = pass2_4x(ps2, v1, low, up_res, batch_norm, vel_scale)    # run 2 scales only vy,vz (quirk of :278-283)
     return v2, v1
 
 
@@ -137,22 +138,3 @@ def multipass_8x(ps_list, cfgs, low, up_res=8, pixel_norm=True, apply_cutoff=Tru
     dim_output = dim_output.transpose(2, 1, 0)                                   # :589-590
     dim_output = np.ascontiguousarray(dim_output)
     return cutoff(dim_output) if apply_cutoff else dim_output
-
-
-# ----------------------------------------------------------------------------
-# synthetic inputs
-# ----------------------------------------------------------------------------
-def synthetic_volume(sim, channels=1, index=0):
-    """Smooth smoke-like density in [0,1] with ~40 % zeros and blurred
-    N(0,0.5^2) velocities; seeds ``default_rng(1234 + index)``."""
-    import scipy.ndimage
-    rng = np.random.default_rng(1234 + index)
-    d = scipy.ndimage.gaussian_filter(rng.random((sim, sim, sim)), 3.0, mode="wrap")
-    d = (d - d.mean()) / (d.std() + 1e-12)
-    d = np.clip(d * 0.5 + 0.1, 0.0, 1.0)
-    vol = np.zeros((sim, sim, sim, channels), dtype=F32)
-    vol[..., 0] = d
-    for c in range(1, channels):
-        v = scipy.ndimage.gaussian_filter(rng.standard_normal((sim, sim, sim)) * 0.5, 2.0, mode="wrap")
-        vol[..., c] = v * 4.0
-    return vol

@@ -1,0 +1,266 @@
+"""GPU parity of each HIP kernel (through the C ABI) against the numpy oracle.
+
+Tolerances: the convolution runs fp16 operands with fp32 accumulation.
+MPG_PREC_F16X3 (hi/lo split, three products) is held to 2e-5 relative L2,
+MPG_PREC_F16X1 to 1.5e-3 per layer; the fp32 element-wise kernels to 1e-6.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, act, pixel_norm
+    (2, 16, 64, 8, 128, 5, "relu", False),
+    (1, 16, 32, 128, 128, 5, None, False),
+    (1, 13, 40, 128, 32, 5, "relu", False),     # ragged tile edges
+    (2, 8, 32, 1, 2, 5, "relu", False),         # tiny channel counts
+    (1, 16, 32, 2, 8, 5, None, False),
+    (1, 24, 32, 6, 128, 3, "relu", True),       # 8x net1 first block + pixel norm
+    (1, 16, 64, 96, 96, 5, "lrelu", True),      # 3 channel chunks, 3 n-tiles
+    (1, 16, 32, 48, 24, 5, None, False),
+    (1, 16, 32, 12, 1, 1, None, False),         # 1x1 to one channel
+    (1, 9, 33, 5, 16, 5, "relu", True),
+    (1, 16, 32, 64, 64, 4, "lrelu", False),     # even kernel: pad 1 before / 2 after
+    (1, 16, 32, 3, 7, 7, "tanh", False),
+]
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 2e-5), (1, 1.5e-3)])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fused_single(gpu_ops, case, prec, tol):
+    n, h, w, cin, cout, k, act, pn = case
+    rng = _rng(1000 + CONV_CASES.index(case))
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = float(O.wscale(wt.shape))
+    ref = O.conv2d_same(x, (wt.astype(np.float64) * ws).astype(np.float32))
+    ref = O.activation(O.bias_add(ref, b), act)
+    if pn:
+        ref = O.pixel_norm(ref)
+    pk = gpu_ops.pack_conv_weights(_t(wt), wscale=ws, prec=prec)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (h, w), bias=_t(b), act=act, pixel_norm=pn)
+    torch.cuda.synchronize()
+    err = rel_l2(y.cpu().numpy(), ref)
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("kc_max,ks", [(8, 2), (16, 4), (24, 2), (32, 4), (32, 2), (16, 2)])
+def test_conv2d_fused_tuning_variants(gpu_ops, kc_max, ks):
+    rng = _rng(kc_max * 10 + ks)
+    x = rng.standard_normal((1, 16, 32, 96)).astype(np.float32)
+    wt = rng.standard_normal((3, 3, 96, 40)).astype(np.float32)
+    ref = O.conv2d_same(x, wt)
+    for prec, tol in ((3, 2e-5), (1, 1.5e-3)):
+        pk = gpu_ops.pack_conv_weights(_t(wt), prec=prec, kc_max=kc_max, ks=ks)
+        y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (16, 32))
+        assert rel_l2(y.cpu().numpy(), ref) < tol
+
+
+def test_conv2d_fused_exact_integers(gpu_ops):
+    """Small-integer data is exact in fp16: the MFMA path must be bit-exact, which pins
+    the fragment layouts (asymmetric weights catch a transposed operand map)."""
+    rng = _rng(7)
+    x = rng.integers(-3, 4, size=(1, 16, 64, 16)).astype(np.float32)
+    wt = rng.integers(-2, 3, size=(5, 5, 16, 40)).astype(np.float32)
+    ref = O.conv2d_same(x, wt)
+    for prec in (1, 3):
+        pk = gpu_ops.pack_conv_weights(_t(wt), prec=prec)
+        y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (16, 64))
+        assert np.array_equal(y.cpu().numpy(), ref)
+
+
+def test_conv2d_fused_impulse_padding(gpu_ops):
+    """Delta input: the output is the flipped kernel around the impulse; checks SAME padding
+    (incl. the asymmetric even-kernel case) at the image corners."""
+    for k in (3, 4, 5):
+        wt = _rng(k).standard_normal((k, k, 1, 4)).astype(np.float32)
+        for (iy, ix) in ((0, 0), (7, 31), (3, 17)):
+            x = np.zeros((1, 8, 32, 1), dtype=np.float32)
+            x[0, iy, ix, 0] = 1.0
+            ref = O.conv2d_same(x, wt)
+            pk = gpu_ops.pack_conv_weights(_t(wt), prec=3)
+            y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (8, 32))
+            assert rel_l2(y.cpu().numpy(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 2e-5), (1, 1.5e-3)])
+def test_conv2d_fused_resblock_segments(gpu_ops, prec, tol):
+    """relu(convB(a) + conv1x1(x)) as one launch with two K-segments (multipassGAN-4x.py:517-523),
+    with batch norm folded into weights and bias (GAN.py:108-110)."""
+    rng = _rng(11)
+    n, h, w = 2, 16, 32
+    a = rng.standard_normal((n, h, w, 32)).astype(np.float32)
+    x = rng.standard_normal((n, h, w, 128)).astype(np.float32)
+    wb = rng.standard_normal((5, 5, 32, 8)).astype(np.float32)
+    wsk = rng.standard_normal((1, 1, 128, 8)).astype(np.float32)
+    bb = rng.standard_normal(8).astype(np.float32)
+    bs = rng.standard_normal(8).astype(np.float32)
+    bn = [dict(g=1 + 0.1 * rng.standard_normal(8), b=0.1 * rng.standard_normal(8), m=0.1 * rng.standard_normal(8),
+               v=1 + 0.2 * rng.random(8)) for _ in range(2)]
+    wsb, wss = float(O.wscale(wb.shape)), float(O.wscale(wsk.shape))
+    rb = O.batch_norm_infer(O.bias_add(O.conv2d_same(a, wb * np.float32(wsb)), bb), bn[0]["g"], bn[0]["b"], bn[0]["m"], bn[0]["v"])
+    rs = O.batch_norm_infer(O.bias_add(O.conv2d_same(x, wsk * np.float32(wss)), bs), bn[1]["g"], bn[1]["b"], bn[1]["m"], bn[1]["v"])
+    ref = O.relu(rb + rs)
+    sc = [d["g"] / np.sqrt(d["v"] + 1e-3) for d in bn]
+    bias = (bb - bn[0]["m"]) * sc[0] + bn[0]["b"] + (bs - bn[1]["m"]) * sc[1] + bn[1]["b"]
+    pkb = gpu_ops.pack_conv_weights(_t(wb), wscale=wsb, cout_scale=_t(sc[0]), prec=prec)
+    pks = gpu_ops.pack_conv_weights(_t(wsk), wscale=wss, cout_scale=_t(sc[1]), prec=prec)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(a), pkb), gpu_ops.Segment(_t(x), pks)], (h, w), bias=_t(bias), act="relu")
+    assert rel_l2(y.cpu().numpy(), ref) < tol
+
+
+def test_conv2d_fused_upsample_concat_postadd(gpu_ops):
+    """conv over concat(y, nearest_x8(x_low)) as two segments (multipassGAN-out.py:357), fused
+    nearest upsample (GAN.py:517) and the final '+ input density' (multipassGAN-out.py:332)."""
+    rng = _rng(13)
+    n, hl, up = 1, 4, 8
+    h = hl * up
+    yprev = rng.standard_normal((n, h, h, 1)).astype(np.float32)
+    xlow = rng.standard_normal((n, hl, hl, 4)).astype(np.float32)
+    wt = rng.standard_normal((5, 5, 5, 16)).astype(np.float32)
+    cat = np.concatenate([yprev, O.resize_nearest_tf1(xlow, h, h)], axis=3)
+    extra = rng.standard_normal((n, h, h, 16)).astype(np.float32)
+    ref = O.conv2d_same(cat, wt) + extra
+    p0 = gpu_ops.pack_conv_weights(_t(wt), c_off=0, cin=1, prec=3)
+    p1 = gpu_ops.pack_conv_weights(_t(wt), c_off=1, cin=4, prec=3)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(yprev), p0), gpu_ops.Segment(_t(xlow), p1, up_log2=3)], (h, h),
+                             post_add=_t(extra))
+    assert rel_l2(y.cpu().numpy(), ref) < 2e-5
+    # channel window of a wider tensor
+    wide = rng.standard_normal((n, h, h, 12)).astype(np.float32)
+    w2 = rng.standard_normal((3, 3, 4, 8)).astype(np.float32)
+    ref2 = O.conv2d_same(wide[..., 4:8], w2)
+    p2 = gpu_ops.pack_conv_weights(_t(w2), prec=3)
+    y2 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(wide), p2, c_off=4)], (h, h))
+    assert rel_l2(y2.cpu().numpy(), ref2) < 2e-5
+
+
+@pytest.mark.parametrize("stride,k,cin,cout", [(1, 5, 3, 6), (2, 4, 2, 32), (2, 4, 32, 64), (1, 4, 128, 16), (2, 3, 5, 7)])
+def test_conv2d_direct(gpu_ops, stride, k, cin, cout):
+    rng = _rng(17 + k + stride)
+    x = rng.standard_normal((2, 16, 18, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = float(O.wscale(wt.shape))
+    ref = O.lrelu(O.bias_add(O.conv2d_same(x, wt * np.float32(ws), (stride, stride)), b))
+    y = gpu_ops.conv2d_direct(_t(x), _t(wt), (stride, stride), wscale=ws, bias=_t(b), act="lrelu")
+    assert y.shape == ref.shape
+    assert rel_l2(y.cpu().numpy(), ref) < 2e-6
+
+
+def test_direct_and_mfma_agree(gpu_ops):
+    """two independent HIP implementations of the same conv"""
+    rng = _rng(19)
+    x = rng.standard_normal((1, 16, 32, 24)).astype(np.float32)
+    wt = rng.standard_normal((3, 3, 24, 48)).astype(np.float32)
+    y1 = gpu_ops.conv2d_direct(_t(x), _t(wt))
+    y2 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), gpu_ops.pack_conv_weights(_t(wt), prec=3))], (16, 32))
+    assert rel_l2(y2.cpu().numpy(), y1.cpu().numpy()) < 2e-5
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("shape,out", [((2, 8, 8, 3), (64, 64)), ((1, 16, 16, 1), (32, 32)), ((1, 5, 7, 2), (20, 14)),
+                                       ((1, 6, 6, 4), (9, 15))])
+def test_resize(gpu_ops, method, shape, out):
+    x = _rng(23).standard_normal(shape).astype(np.float32)
+    ref = O.resize_images_tf1(x, out[0], out[1], method)
+    y = gpu_ops.resize_images(_t(x), out[0], out[1], method)
+    if method == 1:
+        assert np.array_equal(y.cpu().numpy(), ref)
+    else:
+        assert rel_l2(y.cpu().numpy(), ref) < 1e-6
+
+
+def test_bicubic_known_answers(gpu_ops):
+    """constant fields stay constant (weights sum to 1) and integer-aligned samples reproduce
+    the input (TF1 legacy coordinates: dst = 8*src hits src exactly)."""
+    c = np.full((1, 8, 8, 1), 3.25, dtype=np.float32)
+    y = gpu_ops.resize_bicubic(_t(c), 64, 64).cpu().numpy()
+    assert np.abs(y - 3.25).max() < 1e-5
+    x = _rng(29).standard_normal((1, 8, 8, 2)).astype(np.float32)
+    y = gpu_ops.resize_bicubic(_t(x), 64, 64).cpu().numpy()
+    assert np.abs(y[:, ::8, ::8] - x).max() < 1e-6
+
+
+def test_pool_norm_add(gpu_ops):
+    x = _rng(31).standard_normal((2, 16, 12, 5)).astype(np.float32)
+    assert rel_l2(gpu_ops.avg_pool2(_t(x)).cpu().numpy(), O.avg_pool(x)) < 1e-6
+    assert rel_l2(gpu_ops.pixel_norm(_t(x)).cpu().numpy(), O.pixel_norm(x)) < 1e-6
+    b = _rng(37).standard_normal(x.shape).astype(np.float32)
+    assert rel_l2(gpu_ops.add_act(_t(x), _t(b), "relu").cpu().numpy(), O.relu(x + b)) < 1e-7
+    assert rel_l2(gpu_ops.add_act(_t(x), None, "lrelu").cpu().numpy(), O.lrelu(x)) < 1e-6
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("factor", [4, 8])
+def test_axis_zoom_matches_scipy(gpu_ops, axis, factor):
+    import scipy.ndimage
+    v = _rng(41).standard_normal((6, 7, 5, 4)).astype(np.float32)
+    zoom = [1, 1, 1, 1]
+    zoom[axis] = factor
+    ref = scipy.ndimage.zoom(v, zoom, order=1, mode="constant", cval=0.0)
+    y = gpu_ops.axis_zoom_linear(_t(v), axis, factor).cpu().numpy()
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-6
+    assert np.abs(y - O.zoom_axis_linear(v, axis, factor)).max() < 1e-6
+
+
+@pytest.mark.parametrize("perm", [(0, 1, 2), (2, 1, 0), (1, 2, 0), (2, 0, 1), (1, 0, 2), (0, 2, 1)])
+def test_volume_transpose(gpu_ops, perm):
+    v = _rng(43).standard_normal((40, 33, 70)).astype(np.float32)
+    y = gpu_ops.volume_transpose(_t(v), perm).cpu().numpy()
+    assert np.array_equal(y, v.transpose(perm))
+    # with cutoff
+    v2 = np.abs(v) * 0.001
+    y2 = gpu_ops.volume_transpose(_t(v2), perm, cutoff=0.0005).cpu().numpy()
+    ref2 = v2.transpose(perm).copy()
+    ref2[ref2 < 0.0005] = 0
+    assert np.array_equal(y2, ref2)
+    # multi-channel with channel swap (multipassGAN-out.py:472-475)
+    v4 = _rng(47).standard_normal((6, 5, 9, 4)).astype(np.float32)
+    y4 = gpu_ops.volume_transpose(_t(v4), perm, chan_map=[0, 3, 2, 1]).cpu().numpy()
+    assert np.array_equal(y4, v4.transpose(tuple(perm) + (3,))[..., [0, 3, 2, 1]])
+
+
+def test_add_adjacent_and_cutoff(gpu_ops):
+    from oracle import multipass as MP
+    x = _rng(53).standard_normal((6, 4, 5, 4)).astype(np.float32)
+    ref = MP.add_adjacent(x, 4)
+    assert np.array_equal(gpu_ops.add_adjacent(_t(x)).cpu().numpy(), ref)
+    assert np.array_equal(gpu_ops.add_adjacent(_t(x), 2, 3).cpu().numpy(), ref[2:5])
+    v = (_rng(59).random(1000) * 0.001).astype(np.float32)
+    assert np.array_equal(gpu_ops.cutoff(_t(v)).cpu().numpy(), MP.cutoff(v))
+
+
+def test_empty_and_bad_arguments(gpu_ops, mpg):
+    from mpgan_amd._lib import MpgError
+    with pytest.raises(MpgError):
+        gpu_ops.conv2d_direct(torch.zeros(1, 4, 4, 3), torch.zeros(3, 3, 3, 2))      # CPU tensors are refused
+    with pytest.raises(MpgError):
+        gpu_ops.pack_conv_weights(_t(np.zeros((3, 3, 4, 200), np.float32)))          # cout > 128
+    with pytest.raises(MpgError):
+        gpu_ops.volume_transpose(_t(np.zeros((2, 2, 2), np.float32)), (0, 0, 1))
+    x = _t(np.zeros((1, 8, 8, 4), np.float32))
+    pk = gpu_ops.pack_conv_weights(_t(np.zeros((3, 3, 4, 8), np.float32)))
+    with pytest.raises(MpgError):
+        gpu_ops.conv2d_fused([gpu_ops.Segment(x, pk)], (16, 16))                     # shape mismatch
+    assert gpu_ops.axis_zoom_linear(_t(np.zeros((4, 4, 4, 0), np.float32)), 0, 4).shape == (16, 4, 4, 0)
