@@ -48,7 +48,15 @@ class VariableStore(object):
             return (1.0 + 0.2 * rng.random(shape)).astype(np.float32)
         raise G.GraphError("unknown variable kind %r" % (kind,))
 
+    def _place(self, t):
+        # without a GPU (graph building / plan inspection on the build host) values stay on the CPU
+        if self.device.type == "cuda" and not torch.cuda.is_available():
+            return t
+        return t.to(self.device)
+
     def ensure(self, graph):
+        for name in [k for k, v in self.values.items() if v.device != self.device]:
+            self.values[name] = self._place(self.values[name])
         for name, spec in graph.variables.items():
             if name not in self.values:
                 self.set(name, self.synthetic(name, spec.shape, spec.kind, self.seed, self.bn_seed))
@@ -57,7 +65,7 @@ class VariableStore(object):
                                    % (name, tuple(self.values[name].shape), spec.shape))
 
     def set(self, name, value):
-        self.values[name] = torch.as_tensor(np.ascontiguousarray(value), dtype=torch.float32).to(self.device)
+        self.values[name] = self._place(torch.as_tensor(np.ascontiguousarray(value), dtype=torch.float32))
         self.version += 1
 
     def load(self, params, prefix=""):
@@ -94,9 +102,6 @@ class _Plan(object):
 class Session(object):
     def __init__(self, device="cuda:0", prec=ops.DEFAULT_PREC, variables=None, graph=None, kc_max=0, ks=0,
                  prec_map=None):
-        _lib.load()
-        if not torch.cuda.is_available():
-            raise _lib.MpgError("no GPU visible: the multi-pass GAN path has no CPU fallback")
         self.device = torch.device(device)
         self.prec, self.kc_max, self.ks = prec, kc_max, ks
         # per-launch precision override: [(substring of the first term's weight name, prec), ...]
@@ -122,6 +127,9 @@ class Session(object):
 
     def run_device(self, fetch, feeds):
         """device tensors in / device tensor out (what the multi-pass pipeline uses)."""
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MpgError("no GPU visible: the multi-pass GAN path has no CPU fallback")
         self.vars.ensure(self.graph)
         if self._cache_version != self.vars.version:
             self._packed.clear()
@@ -284,7 +292,27 @@ class Session(object):
             return ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
                                     post_add=pa)
 
+        run.info = {
+            "kind": "conv2d_fused", "cout": cout, "act": act, "pixel_norm": pn, "prec": prec,
+            "post_add": post_add.name if post_add is not None else None,
+            "segments": [dict(src=src.name, c_off=c_off_src, cin=cin, up_log2=up, w_off=w_off,
+                              kernel=tuple(term.conv.inputs[1].shape[:2]), weight=term.conv.inputs[1].attrs["var"])
+                         for (src, c_off_src, up, term, w_off, cin) in segs],
+        }
         return deps, run
+
+    def plan_summary(self, fetch):
+        """the launch plan of `fetch` as a list of dicts (no GPU needed): one entry per kernel launch"""
+        plan = self._plans.get(fetch.id) or self._compile(fetch)
+        self._plans[fetch.id] = plan
+        out = []
+        for node, fn in plan.steps:
+            if node.op in ("variable", "placeholder"):
+                continue
+            info = dict(getattr(fn, "info", {"kind": node.op}))
+            info["node"] = node.name
+            out.append(info)
+        return out
 
     def _match_chain(self, n, single_use, top=True):
         """[pixel_norm]([act](lin)) -> (terms, act, leak, pn, eps)."""

@@ -1,0 +1,117 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol
+include/mpgan.h declares; the GAN builder creates the reference's variable names; the
+session fuses the graphs into the expected launches (no GPU, no compute)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(mpg):
+    from mpgan_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mpgan.h")).read()
+    declared = set(re.findall(r"\b(mpg_[a-z0-9_]+)\s*\(", text))
+    declared -= {"mpg_conv_seg", "mpg_conv_desc"}
+    assert len(declared) >= 15
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.PROTOTYPES)
+    assert lib.mpg_version().startswith(b"mpgan-hip")
+    # host-side helper: no GPU needed
+    assert lib.mpg_conv_pack_size(5, 5, 128, 128, 1, 0, 0) == 4 * 13 * 4 * 4 * 1024
+    assert lib.mpg_conv_pack_size(5, 5, 128, 200, 1, 0, 0) == 0
+
+
+def test_struct_layout_matches_header(mpg):
+    import ctypes
+    from mpgan_amd import _lib
+    assert ctypes.sizeof(_lib.ConvSeg) == 40
+    assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 40 + 64
+
+
+def test_compute_refuses_without_gpu(mpg):
+    import torch
+    from mpgan_amd import _lib, ops
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    with pytest.raises(_lib.MpgError):
+        ops.cutoff(torch.zeros(4))
+    from mpgan_amd import multipass as MP
+    g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1), None)
+    with pytest.raises(_lib.MpgError):
+        g(torch.zeros(1, 8, 8, 1))
+
+
+def test_builder_variable_names_match_reference_scopes(mpg):
+    from mpgan_amd import multipass as MP
+    from oracle import nets as ON
+    ps = ON.ParamSource()
+    ON.gen_resnet(ps, np.zeros((1, 4, 4, 4), np.float32), 4, 2, True)
+    g = MP.Generator("gen_resnet", dict(tile_low=4, up_res=4, channels=4, upsampling_mode=2), None)
+    assert list(g.graph.variables) == ps.order
+    assert {k: v.shape for k, v in g.graph.variables.items()} == {k: v.shape for k, v in ps.params.items()}
+    assert "generator/g_cA0/moving_variance" in g.graph.variables and "generator/g_s3/bias" in g.graph.variables
+    cfgs = [dict(first_gen=True, filter_size=3, start_fms=256, max_fms=256, add_adj=True, first_nn_arch=True),
+            dict(first_gen=False, filter_size=5, start_fms=192, max_fms=192),
+            dict(first_gen=False, filter_size=5, start_fms=192, max_fms=96, use_res_net=False)]
+    for c in cfgs:
+        ps = ON.ParamSource()
+        x = np.zeros((1, 4, 4, 6 if c["first_gen"] else 4), np.float32)
+        if c["first_gen"]:
+            ON.growing_gen(ps, x, 8, True, 3, 256, 256, True, True)
+        else:
+            ON.growing_gen(ps, ON.gen2_input(np.zeros((1, 32, 32, 1), np.float32), x, 32), 8, False, c["filter_size"],
+                           c["start_fms"], c["max_fms"], False, c.get("use_res_net", True))
+        g = MP.Generator("growing_gen", dict(tile_low=4, up_res=8, channels=4, **c), None)
+        assert sorted(g.graph.variables) == sorted(ps.params)
+    assert "generator/genBlock8/g_cdensOut8/weight" in g.graph.variables
+
+
+def test_gan_layer_side_effects(mpg):
+    from mpgan_amd import graph as G
+    from mpgan_amd.GAN import GAN, lrelu
+    G.reset_default_graph()
+    x = G.placeholder([None, 8, 8, 3])
+    gan = GAN(x)
+    a, lin = gan.convolutional_layer(16, [3, 3], lrelu, name="c1")
+    assert gan.layer is a and lin.op == "bias_add" and a.attrs["act"] == "lrelu"
+    b, _ = gan.convolutional_layer(4, [1, 1], None, name="c2")           # reads self.layer
+    assert b.inputs[0].inputs[0] is a and gan.layer is b
+    gan.max_depool(height_factor=2, width_factor=2)
+    assert gan.layer.shape == (None, 16, 16, 4)
+    gan.avg_depool(mode=2, scale=[2])
+    assert gan.layer.shape == (None, 32, 32, 4) and gan.layer.attrs["method"] == 2
+    gan.avg_pool()
+    assert gan.layer.shape == (None, 16, 16, 4)
+    n = gan.flatten()
+    assert n == 16 * 16 * 4
+    gan.fully_connected_layer(1, None, name="fc", gain=1)
+    assert gan.y().shape == (None, 1)
+    assert gan.getDOFs() == 3 * 3 * 3 * 16 + 16 + 16 * 4 + 4 + n + 1
+    assert list(G.get_default_graph().variables) == ["c1/weight", "c1/bias", "c2/weight", "c2/bias", "fc/weight", "fc/bias"]
+    with pytest.raises(TypeError):
+        gan.deconvolutional_layer(4, [2, 2])           # unusable in the reference as well (GAN.py:584)
+    G.reset_default_graph()
+
+
+def test_fusion_plan(mpg):
+    from mpgan_amd import multipass as MP
+    g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)
+    launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] == "conv2d_fused"]
+    assert [e["cout"] for e in launches] == [2, 8, 128, 128, 32, 8, 2, 1]
+    assert [len(e["segments"]) for e in launches] == [1, 2, 1, 2, 1, 2, 1, 2]
+    assert launches[0]["segments"][0]["up_log2"] == 2 and launches[1]["segments"][1]["up_log2"] == 2
+    assert all(e["act"] == "relu" for e in launches)
+    other = [e["kind"] for e in g.sess.plan_summary(g.sampler) if e["kind"] != "conv2d_fused"]
+    assert set(other) <= {"reshape"}
+    g2 = MP.Generator("growing_gen", dict(tile_low=8, up_res=8, channels=4, first_gen=False, filter_size=5,
+                                          start_fms=192, max_fms=192), None)
+    plan = [e for e in g2.sess.plan_summary(g2.sampler) if e["kind"] == "conv2d_fused"]
+    # first conv reads concat(y, nearest_x8(x)) as two segments; its resblock partner adds the two 1x1 segments
+    assert [(s["cin"], s["up_log2"]) for s in plan[0]["segments"]] == [(1, 0), (4, 3)]
+    assert [(s["cin"], s["up_log2"], s["kernel"]) for s in plan[1]["segments"]] == [(16, 0, (5, 5)), (1, 0, (1, 1)), (4, 3, (1, 1))]
+    assert plan[-1]["cout"] == 1 and plan[-1]["post_add"] is not None and plan[0]["pixel_norm"]

@@ -1,0 +1,120 @@
+"""Host-side drop-in modules (uniio, paramhelpers, FluidDataLoader) against fixtures produced
+by the reference's own modules (tests/golden/make_golden.py)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "tools_golden.npz"))
+
+
+def _header(uniio, n, vec3):
+    h = uniio.make_header(n, n, n, vec3=vec3, info=b"golden", timestamp=1234567, grid_type=4 if vec3 else 1)
+    return h
+
+
+def test_uni_write_is_byte_identical(mpg, tmp_path):
+    from mpgan_amd import uniio
+    for kind, vec3 in (("scalar", False), ("vec3", True)):
+        p = str(tmp_path / (kind + ".uni"))
+        arr = GOLD["uni_%s_in" % kind]
+        uniio.writeUni(p, _header(uniio, 6, vec3), arr)
+        with gzip.open(p, "rb") as f:
+            raw = np.frombuffer(f.read(), dtype=np.uint8)
+        assert np.array_equal(raw, GOLD["uni_%s_bytes" % kind])      # magic + 288-byte header + payload
+        head, back = uniio.readUni(p)
+        assert np.array_equal(back, arr) and back.shape == arr.shape
+        assert head["dimX"] == 6 and head["elementType"] == (2 if vec3 else 1) and head["timestamp"] == 1234567
+
+
+def test_uni_reads_old_mnt2_header(mpg, tmp_path):
+    from mpgan_amd import uniio
+    p = str(tmp_path / "old.uni")
+    with gzip.open(p, "wb") as f:
+        f.write(GOLD["uni_mnt2_bytes"].tobytes())
+    head, arr = uniio.readUni(p)
+    assert np.array_equal(arr, GOLD["uni_scalar_in"])
+    assert head["dimT"] == int(GOLD["uni_mnt2_dimT"]) and len(head["info"]) == int(GOLD["uni_mnt2_info_len"])
+    # float64 content is converted, wrong magic is refused
+    q = str(tmp_path / "f64.uni")
+    uniio.writeUni(q, _header(uniio, 6, False), GOLD["uni_scalar_in"].astype(np.float64))
+    assert np.array_equal(uniio.readUni(q)[1], GOLD["uni_scalar_in"])
+    with gzip.open(str(tmp_path / "bad.uni"), "wb") as f:
+        f.write(b"XXXX" + bytes(288))
+    with pytest.raises(uniio.UniError):
+        uniio.readUni(str(tmp_path / "bad.uni"))
+
+
+@pytest.fixture()
+def sim_dir(mpg, tmp_path):
+    from mpgan_amd import uniio
+    sim = tmp_path / "sim_1000"
+    sim.mkdir()
+    d_low, v_low, d_hi = GOLD["fdl_d_low"], GOLD["fdl_v_low"], GOLD["fdl_d_hi"]
+    for f in range(d_low.shape[0]):
+        uniio.writeUni(str(sim / ("density_low_%04d.uni" % f)), _header(uniio, 8, False), d_low[f])
+        uniio.writeUni(str(sim / ("velocity_low_%04d.uni" % f)), _header(uniio, 8, True), v_low[f])
+        uniio.writeUni(str(sim / ("density_high_%04d.uni" % f)), _header(uniio, 16, False), d_hi[f])
+    return str(tmp_path) + "/"
+
+
+def test_fluiddataloader_output_mode(mpg, sim_dir):
+    from mpgan_amd.fluiddataloader import FluidDataLoader
+    fl = FluidDataLoader(print_info=0, base_path=sim_dir, base_path_y=sim_dir, numpy_seed=42,
+                         filename="density_low_%04d.uni", filename_index_min=0, oldNamingScheme=False, filename_y=None,
+                         filename_index_max=3, indices=[1000], data_fraction=1.0,
+                         multi_file_list=["density", "velocity"], multi_file_list_y=["density"])
+    x, y, names = fl.get()
+    assert y is None and x.dtype == np.float32
+    assert np.array_equal(x, GOLD["fdl_out_x"])
+    assert [os.path.basename(n) for n in names] == list(GOLD["fdl_out_names"])
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_fluiddataloader_slice_mode(mpg, sim_dir, axis):
+    from mpgan_amd.fluiddataloader import FluidDataLoader
+    fl = FluidDataLoader(print_info=0, base_path=sim_dir, base_path_y=sim_dir, numpy_seed=42, conv_slices=True,
+                         conv_axis=axis, select_random=0.5, density_threshold=0.45,
+                         axis_scaling_y=[0.5, 1, 1, 1] if axis == 0 else [1, 1, 1, 1],
+                         axis_scaling=[1, 1, 1, 1] if axis == 0 else [2, 1, 1, 1],
+                         filename="density_low_%04d.uni", oldNamingScheme=False, filename_y="density_high_%04d.uni",
+                         filename_index_max=3, filename_index_min=0, indices=[1000], data_fraction=1.0,
+                         multi_file_list=["density", "velocity"] * 3, multi_file_idxOff=[0, 0, 1, 1, 2, 2],
+                         multi_file_list_y=["density"] * 3, multi_file_idxOff_y=[0, 1, 2])
+    x, y, _ = fl.get()
+    gx, gy = GOLD["fdl_slices_x_axis%d" % axis], GOLD["fdl_slices_y_axis%d" % axis]
+    assert x.shape == gx.shape and y.shape == gy.shape
+    assert np.array_equal(x, gx) and np.array_equal(y, gy)
+
+
+def test_fluiddataloader_fraction_and_errors(mpg, sim_dir):
+    from mpgan_amd.fluiddataloader import FluidDataLoader, FluidDataLoaderError
+    fl = FluidDataLoader(print_info=0, base_path=sim_dir, base_path_y=sim_dir, numpy_seed=1,
+                         filename="density_low_%04d.uni", filename_index_min=0, filename_index_max=4, indices=[1000],
+                         data_fraction=0.5)
+    x, _, names = fl.get()
+    assert np.array_equal(x, GOLD["fdl_fraction_x"])
+    assert [os.path.basename(n) for n in names] == list(GOLD["fdl_fraction_names"])
+    with pytest.raises(FluidDataLoaderError):
+        FluidDataLoader(print_info=0, base_path=sim_dir, filename="a_%04d.uni", wildcard="x", indices=[1000])
+    with pytest.raises(FluidDataLoaderError):
+        FluidDataLoader(print_info=0, base_path=sim_dir, filename="density_low_%04d.uni", indices=[1000],
+                        filename_index_max=2, multi_file_list=["density", "velocity"], multi_file_idxOff=[0])
+
+
+def test_paramhelpers(mpg, tmp_path, capsys):
+    from mpgan_amd import paramhelpers as ph
+    argv = ["prog", "upRes", "8", "TileSize", "64", "bogus", "1"]
+    del ph.paramUsed[:]
+    assert ph.getParam("upres", 4, argv) == "8"          # case-insensitive, strings returned
+    assert ph.getParam("tileSize", 16, argv) == "64"
+    assert ph.getParam("simSize", 64, argv) == 64        # default passes through untouched
+    with pytest.raises(SystemExit):
+        ph.checkUnusedParams(argv)
+    assert "bogus" in capsys.readouterr().out
+    p, no = ph.getNextGenericPath("out_0001-0002", 0, str(tmp_path) + "/")
+    p2, no2 = ph.getNextGenericPath("out_0001-0002", 0, str(tmp_path) + "/")
+    assert (no, no2) == (0, 1) and os.path.isdir(p) and p2.endswith("out_0001-0002_0001/")
+    ph.writeParams(str(tmp_path / "params.json"))
+    assert ph.readParams(str(tmp_path / "params.json"))["upres"] == "8"
