@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""4x driver, output mode (``out 1``): same ``name value`` command line and files as the
+reference's GAN/multipassGAN-4x.py (params :32-144, generate3DUniForNewNetwork :1090-1169,
+output loop :1634-1646).  One network per invocation, the intermediate volume travels through
+``density_low_2x2_%04d.uni`` exactly as in the reference (example_run_output.py:4-8):
+
+  upsamplingMode 2, upsampledData 0 : zoom z, slices along z  -> density_low_2x2_%04d.uni
+  upsamplingMode 1, upsampledData 1 : slices along x          -> density_low_1x1_%04d.uni
+
+Training mode (``out 0``) is not part of this round's scope (SURVEY.md section 8f ordering).
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+import mpgan_amd  # noqa: E402,F401
+from mpgan_amd import checkpoint, multipass, ops, uniio  # noqa: E402
+from mpgan_amd import fluiddataloader as FDL  # noqa: E402
+from mpgan_amd import paramhelpers as ph  # noqa: E402
+
+# every parameter name of the reference is accepted (ph.checkUnusedParams aborts on unknown ones)
+P = {}
+for name, default in [
+        ("out", False), ("basePath", '../2ddata_gan/'), ("randSeed", 1), ("load_model_test", -1), ("load_model_no", -1),
+        ("simSize", 64), ("tileSize", 16), ("upRes", 4), ("packedSimPath", '/data/share/GANdata/2ddata_sim/'),
+        ("fromSim", 1000), ("toSim", -1), ("dataDim", 2), ("numOut", 200), ("saveOut", False), ("loadOut", -1),
+        ("img", True), ("gif", False), ("ref", False), ("frame_min", 0), ("genModel", 'gen_test'),
+        ("discModel", 'disc_test'), ("learningRate", 0.0002), ("decayLR", False), ("dropout", 1.0),
+        ("dropoutOutput", 1.0), ("adam_beta1", 0.5), ("weight_dld", 1.0), ("lambda", 1.0), ("lambda2", 0.0),
+        ("lambda_f", 1.0), ("lambda2_f", 1.0), ("lambda2_l1", 1.0), ("lambda2_l2", 1.0), ("lambda2_l3", 1.0),
+        ("lambda2_l4", 1.0), ("lambda_t", 1.0), ("lambda_t_l2", 0.0), ("batchSize", 128), ("batchSizeDisc", 128),
+        ("batchSizeGen", 128), ("trainGAN", True), ("trainingEpochs", 100000), ("trainingIterations", 100000),
+        ("discRuns", 1), ("genRuns", 1), ("batchNorm", True), ("bnDecay", 0.999), ("useVelocities", 0),
+        ("useVorticities", 0), ("useFlags", 0), ("useK_Eps_Turb", 0), ("premadeTiles", 0), ("cropOverlap", 0),
+        ("dataAugmentation", 0), ("minScale", 0.85), ("maxScale", 1.15), ("rot", 2), ("flip", 1), ("pretrain", 0),
+        ("pretrainDisc", 0), ("pretrainGen", 0), ("testPathStartNo", 0), ("testInterval", 100), ("numTests", 10),
+        ("outputInterval", 100), ("saveInterval", 200), ("alwaysSave", True), ("keepMax", 3), ("genTestImg", -1),
+        ("note", ""), ("data_fraction", 0.3), ("frame_max", 200), ("adv_flag", True), ("change_velocity", False),
+        ("saveMetaData", 0), ("use_spatialdisc", True), ("clamping", True), ("simLowLength", 64), ("simLowWidth", 64),
+        ("simLowHeight", 64), ("overlappedpixel", 3), ("startIndex", 0), ("useAvgDepool", False), ("avgMode", 0),
+        ("velScale", 1.0), ("upsamplingMode", 2), ("upsampledData", False), ("sliceMode", 0), ("interpMode", 1),
+        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0)]:
+    P[name] = ph.getParam(name, default)
+ph.checkUnusedParams()
+
+outputOnly = int(P["out"]) > 0
+basePath, packedSimPath = P["basePath"], P["packedSimPath"]
+simSizeLow, upRes = int(P["simSize"]), int(P["upRes"])
+fromSim, frame_min, frame_max = int(P["fromSim"]), int(P["frame_min"]), int(P["frame_max"])
+useVelocities, velScale = int(P["useVelocities"]), float(P["velScale"])
+upsampling_mode, upsampled_data = int(P["upsamplingMode"]), int(P["upsampledData"])
+generateUni = int(P["genUni"])
+batch_norm = int(P["batchNorm"]) > 0
+load_model_test, load_model_no = int(P["load_model_test"]), int(P["load_model_no"])
+if not outputOnly:
+    print("ERROR: training mode is not implemented in this build; run with `out 1`")
+    exit(1)
+if upsampling_mode not in (1, 2) or int(P["dataDim"]) != 2 or int(P["useAvgDepool"]):
+    print("ERROR: only upsamplingMode 2 (first network) and 1 (second network) of the 2D slice path are implemented")
+    exit(1)
+simSizeHigh = simSizeLow * upRes
+n_ch = 4 if useVelocities else 1
+device = "cuda:0"
+
+mfl = ["density"] + (["velocity"] if useVelocities else [])
+floader = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=int(P["randSeed"]),
+                              filename="density_low_%04d.uni", filename_index_min=frame_min, oldNamingScheme=False,
+                              filename_y=None, filename_index_max=frame_max, indices=[fromSim], data_fraction=1.0,
+                              multi_file_list=mfl, multi_file_list_y=["density"])
+x, _, _ = floader.get()
+x_2 = None
+if upsampled_data:
+    fl2 = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, numpy_seed=int(P["randSeed"]),
+                              filename="density_low_2x2_%04d.uni", filename_index_min=frame_min, oldNamingScheme=False,
+                              filename_index_max=frame_max, indices=[fromSim], data_fraction=1.0, multi_file_list=["density"])
+    x_2, _, _ = fl2.get()
+
+path = checkpoint.model_path(basePath, load_model_test, load_model_no)
+try:
+    params = checkpoint.load(path)
+    print("Model restored from %s." % path)
+except FileNotFoundError as e:
+    if not int(P["synthWeights"]):
+        print("ERROR: %s" % e)
+        exit(1)
+    params = None
+gen = multipass.Generator("gen_resnet", dict(tile_low=simSizeLow, up_res=upRes, channels=n_ch,
+                                             upsampling_mode=upsampling_mode, batch_norm=batch_norm),
+                          params, device=device, seed=int(P["randSeed"]))
+print('*****OUTPUT ONLY*****')
+s = simSizeHigh
+for layerno in range(frame_min, frame_max):
+    i = layerno - frame_min
+    start = time.time()
+    low = torch.as_tensor(np.ascontiguousarray(x[i])).to(device)
+    if upsampling_mode == 2:
+        if n_ch > 1:
+            low[..., 1:4] *= velScale                                        # 4x.py:283
+        xs = ops.axis_zoom_linear(low, 0, upRes)                             # 4x.py:1103
+        out = multipass._run_pass(gen, xs, None, 0, s, 8)                    # (z, y, x)
+        vol = ops.cutoff(out, multipass.CUTOFF) if generateUni else out
+        name = 'density_low_2x2_%04d.uni'
+    else:
+        v1 = torch.as_tensor(np.ascontiguousarray(x_2[i][..., 0])).to(device)
+        if n_ch > 1:
+            vel = (low[..., 1:4] * float(upRes)).contiguous()                # 4x.py:278
+            vel[..., 1:3] *= velScale                                        # 4x.py:283 (vy, vz of the 3-channel array)
+            for ax in range(3):
+                vel = ops.axis_zoom_linear(vel, ax, upRes)                   # 4x.py:1095
+            xin = ops.volume_transpose(torch.cat([v1.reshape(s, s, s, 1), vel], dim=3), (2, 0, 1), chan_map=[0, 2, 3, 1])
+        else:
+            xin = ops.volume_transpose(v1, (2, 0, 1)).reshape(s, s, s, 1)
+        out = multipass._run_pass(gen, xin, None, 0, s, 8)
+        vol = ops.volume_transpose(out, (1, 2, 0), cutoff=multipass.CUTOFF if generateUni else 0.0)
+        name = 'density_low_1x1_%04d.uni'
+    torch.cuda.synchronize()
+    print(time.time() - start)
+    if generateUni:
+        head, _ = uniio.readUni(packedSimPath + "sim_%04d/density_low_%04d.uni" % (fromSim, layerno))
+        head['dimX'] = head['dimY'] = head['dimZ'] = simSizeHigh
+        uniio.writeUni(packedSimPath + '/sim_%04d/' % fromSim + name % layerno, head, vol.cpu().numpy())
+    print('')
+print('Test finished, %d volumes written to %s.' % (frame_max - frame_min, packedSimPath))

@@ -88,7 +88,12 @@ def cpu_baseline(p1, p2, low, slices=6):
     from oracle import multipass as OM
     from oracle import ops as O
     from oracle import torch_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host (16 cores), not all of os.cpu_count()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, int(os.environ.get("MPG_CPU_THREADS", "16")))))
     xs = O.zoom_axis_linear(low, 0, UP)[S // 2 - slices // 2: S // 2 - slices // 2 + slices]
     torch_ref.gen_resnet(p1, xs[:1], UP, 2, True)      # warm up oneDNN
     t0 = time.time()
