@@ -7,7 +7,8 @@
  * relative to the reference tree.
  *
  * Conventions
- *   - all tensors are dense NHWC float32 in device memory (HBM) unless noted;
+ *   - tensors are dense NHWC float32 in device memory (HBM) unless noted (the
+ *     fused convolution reads its inputs in the G8 layout defined below);
  *     pointers are borrowed, the caller (PyTorch-ROCm or any HIP program) owns
  *     the memory;
  *   - `stream` is a hipStream_t passed as void*; every call only enqueues work
@@ -44,6 +45,19 @@ int mpg_device_info(int* cu_count, char* arch_name, int arch_name_len);
 const char* mpg_version(void);
 
 /* ------------------------------------------------------------------------
+ * "G8" activation tensors: what fused convolutions exchange.
+ *     [N][CG = ceil(C/8)][2 planes: hi, lo][H][W][8 x fp16],   value = hi + lo
+ * (two fp16 numbers per value, exact to 2^-22; channels beyond C are zero).
+ * Channel-group-major, so a tile row of one group is a contiguous run of
+ * 16-byte pixels that LDS-DMA can stream.
+ * ------------------------------------------------------------------------ */
+size_t mpg_g8_bytes(int n, int h, int w, int c);
+/* fp32 NHWC x[..., c_off : c_off+cin] -> G8 with ceil(cin/8) groups */
+int mpg_f32_to_g8(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin, void* out);
+/* G8 (c channels) -> fp32 NHWC */
+int mpg_g8_to_f32(mpg_stream_t stream, const void* g8, int n, int h, int w, int c, float* y);
+
+/* ------------------------------------------------------------------------
  * Fused convolution  (replaces GAN.convolutional_layer = tf.nn.conv2d SAME +
  * bias + batch_norm(inference) + activation, tools_wscale/GAN.py:80-119,686-691;
  * the residual sum relu(convB(.) + conv1x1(.)) of resBlock,
@@ -51,21 +65,22 @@ const char* mpg_version(void);
  * GAN.pixel_norm, GAN.py:472-474; the nearest upsample in front of a block,
  * GAN.py:501-523,541; the channel concat of x_in_2, multipassGAN-out.py:357.)
  *
- *   y = post( act( sum_s conv_SAME(up_s(x_s)[..., c_off_s : c_off_s+cin_s], W_s) + bias ) ) + post_add
+ *   y = post( act( sum_s conv_SAME(up_s(x_s)[groups g_off_s ..], W_s) + bias ) ) + post_add
  *
  * stride 1, SAME padding (pad_before = (k-1)/2, extra pad bottom/right).
  * Each segment s contributes one K-slice of the implicit GEMM: a residual
  * shortcut is a 1x1 segment, a channel concat is two segments with the same
  * kernel size, a fused nearest upsample is up_log2 > 0.
+ * The result is written as fp32 NHWC (y), as G8 (y_g8), or both.
  * ------------------------------------------------------------------------ */
 #define MPG_MAX_SEG 4
 
 typedef struct mpg_conv_seg {
-    const float* x;      /* [N, H>>up_log2, W>>up_log2, cin_stride] */
-    const void*  wpack;  /* from mpg_conv_pack_weights, same prec/kc/ks as the launch */
-    int32_t cin;         /* channels consumed */
-    int32_t cin_stride;  /* channels per pixel of x */
-    int32_t c_off;       /* first channel consumed */
+    const void* x;       /* G8 [N][cgroups][2][H>>up_log2][W>>up_log2][8] */
+    const void* wpack;   /* from mpg_conv_pack_weights (same cout and prec as the launch) */
+    int32_t cin;         /* channels consumed, starting at channel 8*g_off of x */
+    int32_t cgroups;     /* channel groups of x */
+    int32_t g_off;       /* first group consumed */
     int32_t kh, kw;      /* kernel size, 1..7 */
     int32_t up_log2;     /* fused nearest upsample: src = (y >> up_log2, x >> up_log2) */
 } mpg_conv_seg;
@@ -80,17 +95,17 @@ typedef struct mpg_conv_desc {
     float   leak;             /* lrelu leak (0.2 in the reference) */
     int32_t pixel_norm;       /* 1: y *= rsqrt(mean_c(y^2) + pn_eps) after act */
     float   pn_eps;           /* 1e-8 */
-    const float* post_add;    /* optional [N,H,W,post_add_stride], channels post_add_coff.. added last */
+    const float* post_add;    /* optional fp32 [N,H,W,post_add_stride], channels post_add_coff.. added last */
     int32_t post_add_stride;
     int32_t post_add_coff;
-    float*  y;                /* [N,H,W,cout] */
+    float*  y;                /* fp32 NHWC [N,H,W,cout] or NULL */
+    void*   y_g8;             /* G8 with ceil(cout/8) groups or NULL (at least one output) */
     int32_t prec;             /* MPG_PREC_* */
-    int32_t kc_max;           /* tuning: max input channels per LDS chunk (8,16,24,32); 0 = default */
-    int32_t ks;               /* tuning: k-steps (of 16) per weight stage (2 or 4); 0 = default */
+    int32_t reserved;         /* must be 0 */
 } mpg_conv_desc;
 
 /* bytes of the packed weight image of one segment. */
-size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec, int kc_max, int ks);
+size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec);
 
 /* Pack W[kh,kw,w_cin_total,cout] (HWIO fp32, device; GAN.py:93) channels
  * [w_c_off, w_c_off+cin) into the MFMA fragment order, multiplying by the
@@ -99,7 +114,7 @@ size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec, int kc_ma
 int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw,
                           int w_cin_total, int w_c_off, int cin, int cout,
                           float wscale, const float* cout_scale,
-                          int prec, int kc_max, int ks, void* out, size_t out_bytes);
+                          int prec, void* out, size_t out_bytes);
 
 int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* desc);
 

@@ -33,8 +33,8 @@ class ConvSeg(ctypes.Structure):
         ("x", ctypes.c_void_p),
         ("wpack", ctypes.c_void_p),
         ("cin", ctypes.c_int32),
-        ("cin_stride", ctypes.c_int32),
-        ("c_off", ctypes.c_int32),
+        ("cgroups", ctypes.c_int32),
+        ("g_off", ctypes.c_int32),
         ("kh", ctypes.c_int32),
         ("kw", ctypes.c_int32),
         ("up_log2", ctypes.c_int32),
@@ -58,9 +58,9 @@ class ConvDesc(ctypes.Structure):
         ("post_add_stride", ctypes.c_int32),
         ("post_add_coff", ctypes.c_int32),
         ("y", ctypes.c_void_p),
+        ("y_g8", ctypes.c_void_p),
         ("prec", ctypes.c_int32),
-        ("kc_max", ctypes.c_int32),
-        ("ks", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -74,8 +74,11 @@ PROTOTYPES = {
     "mpg_last_error": (ctypes.c_char_p, []),
     "mpg_version": (ctypes.c_char_p, []),
     "mpg_device_info": (_I, [ctypes.POINTER(_I), ctypes.c_char_p, _I]),
-    "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
-    "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _I, _P, _Z]),
+    "mpg_g8_bytes": (_Z, [_I, _I, _I, _I]),
+    "mpg_f32_to_g8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mpg_g8_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I]),
+    "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _Z]),
     "mpg_conv2d_fused": (_I, [_P, ctypes.POINTER(ConvDesc)]),
     "mpg_conv2d_direct": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _F, _P]),
     "mpg_resize_nearest": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),

@@ -1,20 +1,25 @@
 // Fused implicit-GEMM convolution on the gfx950 matrix cores.
 //
-// One workgroup (4 waves) produces an 8 x 32 pixel tile of ALL output
-// channels (<= 128).  The contraction index K runs over (segment, channel
-// chunk, tap, 8-channel group); for every channel chunk the input tile with
-// its halo is staged ONCE in LDS as fp16 [pixel][channel] (im2col-free: the
-// 25 taps of a 5x5 kernel are 25 shifted windows of the same LDS image) and
-// the pre-packed fp16 weights are streamed through a double-buffered LDS
-// stage.  v_mfma_f32_32x32x16_f16 computes D[cout][pixel] += W[cout][k] * X[k][pixel]:
-// the weights are the A operand, the pixels the B operand, so that each lane
-// ends up with 4 consecutive output channels of one pixel per accumulator
-// quad (16-byte NHWC stores).
+// Data layout.  Activations travel between fused convolutions as "G8" tensors:
+//     [N][CG = ceil(C/8)][2 planes: hi, lo][H][W][8 x fp16]
+// (value = hi + lo, both fp16, exact to 2^-22; channels beyond C are zero).  A channel group of
+// a tile row is therefore a contiguous run of 16-byte pixels, so the input tile with its halo AND
+// the pre-packed weights both stream into LDS by LDS-DMA (global_load_lds_dwordx4): no VALU, no
+// staging registers, deep prefetch.  fp32 NHWC enters / leaves through mpg_f32_to_g8 and the
+// optional fp32 output of the epilogue.
 //
-// Replaces tf.nn.conv2d + bias + batch_norm + activation (+ residual 1x1 conv,
-// + pixel_norm, + nearest upsample, + channel concat) of
-// tools_wscale/GAN.py:80-119,472-474,501-541 and GAN/multipassGAN-4x.py:505-526,
-// GAN/multipassGAN-out.py:220-237,357 (reference tree).
+// Work decomposition.  One workgroup = 4 waves = (4*PT) x 32 output pixels x all NT*32 output
+// channels; wave w owns tile rows [PT*w, PT*w+PT) (PT pixel tiles of 32 pixels) x NT cout tiles.
+// v_mfma_f32_32x32x16_f16 computes D[cout][pixel] += W[cout][k] * X[k][pixel] (weights = A operand,
+// pixels = B operand), so a lane ends with 4 consecutive channels of one pixel per accumulator quad.
+// K runs over (segment, chunk of CGC channel groups, tap, group): per chunk the halo image of the
+// tile is DMA'd once ([group][plane][pixel][16 B], conflict-free ds_read_b128) and double-buffered,
+// the kh*kw taps are shifted windows of that image (im2col-free); weight stages (KS k-steps of 16)
+// stream through a ring of R LDS slots, D = R-1 stages ahead of the MFMAs, one barrier per stage.
+//
+// Replaces tf.nn.conv2d + bias + batch_norm + activation (+ residual 1x1 conv, + pixel_norm,
+// + nearest upsample, + channel concat) of tools_wscale/GAN.py:80-119,472-474,501-541 and
+// GAN/multipassGAN-4x.py:505-526, GAN/multipassGAN-out.py:220-237,357 (reference tree).
 #include "mpgan_internal.h"
 
 namespace {
@@ -22,18 +27,21 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TH = 8;     // tile rows
-constexpr int TW = 32;    // tile cols == MFMA N dimension
-constexpr int TAPOFF_BYTES = 1024;
+constexpr int TW = 32;              // tile cols == MFMA N dimension
+constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
 struct SegArgs {
-    const float* x;
-    const char* w;
-    int cin, cin_stride, c_off, kh, kw, up;
-    int kc, g, nchunks, sc, ps;
-    int oy, ox;     // window origin of this segment inside the halo tile
-    int hs, ws;     // source height / width (h >> up, w >> up)
-    int vec4;       // 16-byte aligned channel vectors
+    const char* x;        // G8 tensor
+    const char* w;        // packed weights
+    int cg_seg;           // channel groups consumed
+    int cg_total, g_off;  // groups of the tensor, first group consumed
+    int kh, kw, up;
+    int cgc, nchunks, sc; // groups per chunk, chunks, weight stages per chunk
+    int ih, iw;           // LDS image: (TH + kh - 1) x (TW + kw - 1) pixels
+    int pt, pl;           // SAME padding before
+    int hs, ws;           // source height / width (h >> up, w >> up)
+    int np;               // pixels per image plane, padded to a multiple of 64
+    int ni_img;           // image DMA instructions per thread per chunk
 };
 
 struct ConvArgs {
@@ -46,39 +54,64 @@ struct ConvArgs {
     float pn_eps;
     const float* post_add;
     int pa_stride, pa_coff;
-    float* y;
-    int halo_h, halo_w, pad_t, pad_l;
-    int in_plane;   // bytes of one LDS halo plane (max over segments)
+    float* y;             // fp32 NHWC output or null
+    char* y_g8;           // G8 output or null
+    const char* zeros;    // >= 16 zero bytes (source of out-of-image pixels)
+    int img_bytes;        // bytes of one LDS image buffer (max over segments)
     int tiles_x, tiles_y;
+    int dbg;              // development probes: 1 skip K loop, 2 skip stores
 };
 
-// The argument block is read through the kernarg segment pointer (constant address space,
-// scalar loads) so that the runtime-indexed segment table never lands in scratch.
 typedef const __attribute__((address_space(4))) ConvArgs* KArgs;
-typedef const __attribute__((address_space(4))) SegArgs* KSeg;
 
-template <int NT, int PREC, int KS>
+// Per (NT, PREC) pipeline shape (host mirror: pipe_shape()).
+template <int NT, int PREC>
+struct Pipe {
+    static constexpr int NPL = (PREC == 3) ? 2 : 1;
+    static constexpr int PT = (NT >= 3) ? 2 : 4;       // pixel tiles (tile rows) per wave
+    static constexpr int TH = 4 * PT;                  // tile rows per workgroup
+    static constexpr int KS = (PREC == 3) ? ((NT == 4 || NT == 2) ? 1 : 2) : ((NT == 4 || NT == 2) ? 2 : 4);
+    static constexpr int R = (NT == 3) ? 3 : 4;
+    static constexpr int D = R - 1;
+    static constexpr int WPLANE = KS * NT * 1024;
+    static constexpr int WSTAGE = WPLANE * NPL;
+    static constexpr int NI = WSTAGE / 4096;
+    static_assert(WSTAGE % 4096 == 0, "stage must be a whole number of 256 x 16-byte pieces");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_dma_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
+    // lane l of the wave copies 16 bytes from its own `src` to lds_wave_base + 16*l
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int NT, int PREC>
 __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const ConvArgs a_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const auto& a = *ap;
-    constexpr int NPL = (PREC == 3) ? 2 : 1;
-    constexpr int WPLANE = KS * NT * 1024;          // bytes of one weight plane per stage
-    constexpr int WSTAGE = WPLANE * NPL;            // bytes per stage (hi [+ lo])
-    constexpr int NPASS = (WSTAGE + 4095) / 4096;   // 16-B copies per thread per stage
+    using P = Pipe<NT, PREC>;
+    constexpr int PT = P::PT, TH = P::TH, KS = P::KS, WPLANE = P::WPLANE, WSTAGE = P::WSTAGE;
+    constexpr int NI = P::NI, R = P::R, D = P::D;
 
     int* tapoff = reinterpret_cast<int*>(smem);
-    char* in_lds = smem + TAPOFF_BYTES;
-    char* w_lds = in_lds + a.in_plane * NPL;
+    char* img_lds = smem + TAPOFF_BYTES;              // two image buffers
+    char* w_lds = img_lds + 2 * a.img_bytes;          // ring of R stage slots
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int r = lane & 31;
     const int hh = lane >> 5;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
-    // each XCD a contiguous run of tiles => neighbouring halos hit the same L2.
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles => neighbouring halos hit the same L2.
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
@@ -88,110 +121,95 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
     const int n = t2 / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[PT][NT];
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt)
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pt][nt][i] = 0.f;
 
-    const int halo_px = a.halo_h * a.halo_w;
-
-    for (int s = 0; s < a.nseg; ++s) {
+    for (int s = 0; s < ((a.dbg & 1) ? 0 : a.nseg); ++s) {
         const auto& sg = ap->seg[s];
-        const int G = sg.g;
-        const int TG = sg.kh * sg.kw * G;
-        const int ps = sg.ps;
+        const int CGC = sg.cgc;
+        const int TG = sg.kh * sg.kw * CGC;
+        const int plane_b = sg.np * 16;             // bytes of one image plane
+        const int group_b = plane_b * 2;            // hi + lo
+        const int ppg = sg.np >> 6;                 // 1-KiB pieces per plane
 
-        // tap/group -> LDS byte offset table (all waves passed the previous stage barrier)
+        // tap/group -> LDS byte offset inside an image buffer
         for (int q = tid; q < sg.sc * KS * 2; q += 256) {
             int off = 0;
             if (q < TG) {
-                const int tap = q / G;
-                const int g = q - tap * G;
+                const int tap = q / CGC;
+                const int g = q - tap * CGC;
                 const int dy = tap / sg.kw;
                 const int dx = tap - dy * sg.kw;
-                off = ((dy + sg.oy) * a.halo_w + dx + sg.ox) * ps + g * 16;
+                off = (dy * sg.iw + dx) * 16 + g * group_b;
             }
             tapoff[q] = off;
         }
-        const int pixb0 = ((2 * wave) * a.halo_w + r) * ps;
-        const int pixb1 = pixb0 + a.halo_w * ps;
+        int pixb[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) pixb[pt] = ((PT * wave + pt) * sg.iw + r) * 16;
 
-        // weight stages are contiguous over (chunk, stage): stream them through a 2-deep LDS ring,
-        // always one stage ahead (the prefetch of the last stage re-reads it: no branch, no hazard)
-        const int total_stages = sg.nchunks * sg.sc;
-        auto stage_off = [&](int i) -> int {   // byte offset of this thread's i-th 16-B piece, clamped
-            const int o = (i * 256 + tid) * 16;
-            return o < WSTAGE ? o : WSTAGE - 16;
-        };
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int o = stage_off(i);
-            *reinterpret_cast<uint4*>(w_lds + o) = *reinterpret_cast<const uint4*>(sg.w + o);
-        }
-        int cur = 0;
-        for (int ch = 0; ch < sg.nchunks; ++ch) {
-            // ---- stage the input halo tile of this channel chunk (fp32 -> fp16 hi[/lo]) ----
-            for (int idx = tid; idx < halo_px * G; idx += 256) {
-                const int p = idx / G;
-                const int g = idx - p * G;
-                const int hy = p / a.halo_w;
-                const int hx = p - hy * a.halo_w;
-                const int yy = y0 - a.pad_t + hy;
-                const int xx = x0 - a.pad_l + hx;
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
-                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
-                    const int c = ch * sg.kc + g * 8;
-                    const int rem = sg.cin - c;
-                    const float* src = sg.x +
-                        ((size_t)(n * sg.hs + (yy >> sg.up)) * sg.ws + (xx >> sg.up)) * sg.cin_stride + sg.c_off + c;
-                    if (rem >= 8 && sg.vec4) {
-                        const float4 a0 = *reinterpret_cast<const float4*>(src);
-                        const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
-                        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w;
-                        v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (j < rem) v[j] = src[j];
-                    }
-                }
-                half8 hi;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) hi[j] = (_Float16)v[j];
-                *reinterpret_cast<half8*>(in_lds + p * ps + g * 16) = hi;
-                if (PREC == 3) {
-                    half8 lo;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) lo[j] = (_Float16)(v[j] - (float)hi[j]);
-                    *reinterpret_cast<half8*>(in_lds + a.in_plane + p * ps + g * 16) = lo;
-                }
+        // ---- image DMA: piece pc = 4*i + wave covers 64 pixels of one plane of one group ----
+        const size_t plane_px = (size_t)sg.hs * sg.ws;
+        auto dma_image = [&](int chunk) {
+            char* buf = img_lds + (chunk & 1) * a.img_bytes;
+            for (int i = 0; i < sg.ni_img; ++i) {
+                const int pc = 4 * i + wave_u;                 // piece of this wave
+                const int g = pc / (2 * ppg);                  // group within the chunk
+                const int rem = pc - g * 2 * ppg;
+                const int pl = rem / ppg;                      // plane: 0 hi, 1 lo
+                const int p = (rem - pl * ppg) * 64 + lane;    // pixel of the halo image
+                const int hy = p / sg.iw;
+                const int hx = p - hy * sg.iw;
+                const int yy = y0 - sg.pt + hy;
+                const int xx = x0 - sg.pl + hx;
+                const int grp = chunk * CGC + g;
+                const char* src = a.zeros;
+                if (g < CGC && grp < sg.cg_seg && hy < sg.ih && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w &&
+                    (PREC == 3 || pl == 0))
+                    src = sg.x + ((((size_t)n * sg.cg_total + sg.g_off + grp) * 2 + pl) * plane_px +
+                                  (size_t)(yy >> sg.up) * sg.ws + (xx >> sg.up)) * 16;
+                dma16(src, buf + pc * 1024);
             }
-            __syncthreads();
+        };
+        // ---- weight DMA: stage -> ring slot, linear copy ----
+        const int total_stages = sg.nchunks * sg.sc;
+        auto dma_stage = [&](int stage) {
+            const int sidx = stage < total_stages ? stage : total_stages - 1;   // tail: harmless re-read
+            const char* src = sg.w + (size_t)sidx * WSTAGE + tid * 16;
+            char* dst = w_lds + (stage % R) * WSTAGE + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dma16(src + i * 4096, dst + i * 4096);
+        };
 
+        dma_image(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) dma_stage(d);
+
+        for (int ch = 0; ch < sg.nchunks; ++ch) {
+            // short chunks: the image of this chunk was issued fewer than D-1 stages ago
+            if (sg.sc < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* img = img_lds + (ch & 1) * a.img_bytes;
             for (int st = 0; st < sg.sc; ++st) {
                 const int gst = ch * sg.sc + st;
-                const int nst = gst + 1 < total_stages ? gst + 1 : gst;
-                uint4 pre[NPASS];
-                {
-                    const char* wn = sg.w + (size_t)nst * WSTAGE;
-#pragma unroll
-                    for (int i = 0; i < NPASS; ++i) pre[i] = *reinterpret_cast<const uint4*>(wn + stage_off(i));
-                }
-                const char* wb = w_lds + cur * WSTAGE;
+                // stage gst (and everything older, incl. this chunk's image) has landed; all waves are
+                // done with stage gst-1 and, at st == 0, with the previous chunk's image
+                wait_dma_and_barrier<(D - 1) * NI>();
+                if (st == 0 && ch + 1 < sg.nchunks) dma_image(ch + 1);
+                dma_stage(gst + D);
+                const char* wb = w_lds + (gst % R) * WSTAGE;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int toff = tapoff[2 * (st * KS + ks) + hh];
-                    half8 b_hi[2], b_lo[2], a_hi[NT], a_lo[NT];
-                    b_hi[0] = *reinterpret_cast<const half8*>(in_lds + pixb0 + toff);
-                    b_hi[1] = *reinterpret_cast<const half8*>(in_lds + pixb1 + toff);
-                    if (PREC == 3) {
-                        b_lo[0] = *reinterpret_cast<const half8*>(in_lds + a.in_plane + pixb0 + toff);
-                        b_lo[1] = *reinterpret_cast<const half8*>(in_lds + a.in_plane + pixb1 + toff);
+                    half8 b_hi[PT], b_lo[PT], a_hi[NT], a_lo[NT];
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        b_hi[pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + toff);
+                        if (PREC == 3) b_lo[pt] = *reinterpret_cast<const half8*>(img + plane_b + pixb[pt] + toff);
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                        for (int pt = 0; pt < 2; ++pt) {
+                        for (int pt = 0; pt < PT; ++pt) {
                             acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[nt], b_hi[pt], acc[pt][nt], 0, 0, 0);
                             if (PREC == 3) {
                                 acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[nt], b_hi[pt], acc[pt][nt], 0, 0, 0);
@@ -210,35 +228,40 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
                             }
                         }
                 }
-                {
-                    char* wd = w_lds + (cur ^ 1) * WSTAGE;
-#pragma unroll
-                    for (int i = 0; i < NPASS; ++i) *reinterpret_cast<uint4*>(wd + stage_off(i)) = pre[i];
-                }
-                __syncthreads();
-                cur ^= 1;
             }
         }
+        // drain the tail re-reads before the buffers (or the epilogue staging) are reused
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
 
-    // ---------------- epilogue: bias, activation, pixel norm, post add, NHWC store ----------------
+    // ---------------- epilogue: bias, activation, pixel norm, post add, stores ----------------
     // accumulator element i of n-tile nt: output channel nt*32 + 8*(i>>2) + 4*hh + (i&3), pixel r.
-    const int px = x0 + r;
+    constexpr int ROWF = NT * 32 + 4;
+    float* stg = reinterpret_cast<float*>(smem + TAPOFF_BYTES) + wave * (32 * ROWF);
+    const int cg_out = (a.cout + 7) >> 3;
 #pragma unroll
-    for (int pt = 0; pt < 2; ++pt) {
-        const int py = y0 + 2 * wave + pt;
+    for (int pt = 0; pt < PT; ++pt) {
+        const int py = y0 + PT * wave + pt;
         float ss = 0.f;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int co = nt * 32 + 8 * (i >> 2) + 4 * hh + (i & 3);
-                float v = acc[pt][nt][i];
-                if (a.bias != nullptr && co < a.cout) v += a.bias[co];
-                v = mpg::apply_act(v, a.act, a.leak);
-                if (co >= a.cout) v = 0.f;
-                acc[pt][nt][i] = v;
-                ss += v * v;
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (co0 + i < a.cout) b4[i] = a.bias[co0 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = mpg::apply_act(acc[pt][nt][4 * q4 + i] + b4[i], a.act, a.leak);
+                    if (co0 + i >= a.cout) v = 0.f;
+                    acc[pt][nt][4 * q4 + i] = v;
+                    ss += v * v;
+                }
             }
         if (a.pn) {
             ss += __shfl_xor(ss, 32);
@@ -248,29 +271,63 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[pt][nt][i] *= sc;
         }
-        if (py < a.h && px < a.w) {
-            const size_t pix = ((size_t)n * a.h + py) * a.w + px;
-            float* dst = a.y + pix * a.cout;
-            const float* pa = a.post_add ? a.post_add + pix * a.pa_stride + a.pa_coff : nullptr;
+        // stage this wave's 32 pixels x cout through LDS ([pixel][cout] rows padded by 16 B); the 32
+        // pixels of a tile row are contiguous in every output layout, so all stores are whole runs
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int co0 = nt * 32 + 8 * q4 + 4 * hh;
-                    float o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        o[i] = acc[pt][nt][4 * q4 + i];
-                        if (pa != nullptr && co0 + i < a.cout) o[i] += pa[co0 + i];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<float4*>(stg + r * ROWF + co0) =
+                    make_float4(acc[pt][nt][4 * q4], acc[pt][nt][4 * q4 + 1], acc[pt][nt][4 * q4 + 2], acc[pt][nt][4 * q4 + 3]);
+            }
+        if (py < a.h && !(a.dbg & 2)) {
+            const int npx = min(32, a.w - x0);
+            const size_t pix0 = ((size_t)n * a.h + py) * a.w + x0;
+            if (a.post_add != nullptr) {
+                // add into the staged tile first, so both output formats carry it
+                const float* pa = a.post_add + pix0 * a.pa_stride + a.pa_coff;
+                for (int f = lane; f < npx * a.cout; f += 64) {
+                    const int p = f / a.cout;
+                    const int c = f - p * a.cout;
+                    stg[p * ROWF + c] += pa[(size_t)p * a.pa_stride + c];
+                }
+            }
+            if (a.y != nullptr) {
+                float* dst = a.y + pix0 * a.cout;
+                const int total = npx * a.cout;
+                if ((a.cout & 3) == 0) {
+                    for (int f = lane * 4; f < total; f += 256) {
+                        const int p = f / a.cout;
+                        const int c = f - p * a.cout;
+                        *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(stg + p * ROWF + c);
                     }
-                    if ((a.cout & 3) == 0) {
-                        if (co0 < a.cout) *reinterpret_cast<float4*>(dst + co0) = make_float4(o[0], o[1], o[2], o[3]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (co0 + i < a.cout) dst[co0 + i] = o[i];
+                } else {
+                    for (int f = lane; f < total; f += 64) {
+                        const int p = f / a.cout;
+                        dst[f] = stg[p * ROWF + (f - p * a.cout)];
                     }
                 }
+            }
+            if (a.y_g8 != nullptr) {
+                // lanes 0-31 write the hi plane, lanes 32-63 the lo plane of pixel r: 512-byte runs
+                const size_t plane_px = (size_t)a.h * a.w;
+                if (r < npx) {
+                    for (int cg = 0; cg < cg_out; ++cg) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        half8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const _Float16 hi = (_Float16)v[j];
+                            o[j] = hh ? (_Float16)(v[j] - (float)hi) : hi;
+                        }
+                        char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                        *reinterpret_cast<half8*>(dst) = o;
+                    }
+                }
+            }
         }
     }
 }
@@ -278,7 +335,7 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
 // weights HWIO fp32 -> per (chunk, stage) fragment-ordered fp16 hi [lo] planes
 __global__ void pack_weights_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                     int cin, int cout, float wscale, const float* __restrict__ cscale,
-                                    int NT, int KS, int NPL, int kc, int g, int nchunks, int sc,
+                                    int NT, int KS, int NPL, int cgc, int nchunks, int sc,
                                     _Float16* __restrict__ out) {
     const long total = (long)nchunks * sc * KS * NT * 512;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,10 +350,10 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int kh, int kw,
     const int r = lane & 31, hh = lane >> 5;
     const int q = 2 * (st * KS + ks) + hh;
     float v = 0.f;
-    if (q < kh * kw * g) {
-        const int tap = q / g;
-        const int gg = q - tap * g;
-        const int chn = c * kc + gg * 8 + j;
+    if (q < kh * kw * cgc) {
+        const int tap = q / cgc;
+        const int gg = q - tap * cgc;
+        const int chn = (c * cgc + gg) * 8 + j;
         const int co = nt * 32 + r;
         if (chn < cin && co < cout) {
             v = w[((size_t)tap * cin_total + c_off + chn) * cout + co] * wscale;
@@ -311,73 +368,179 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int kh, int kw,
     if (NPL == 2) out[stage * plane * NPL + plane + off] = (_Float16)(v - (float)hi);
 }
 
-template <int NT, int PREC>
-int launch_ks(int ks, dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
-    // dynamic LDS beyond the 64 KiB default needs the per-function opt-in
-    if (ks == 2) {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, PREC, 2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_mfma_kernel<NT, PREC, 2>), grid, dim3(256), lds, st, a);
-    } else {
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, PREC, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((conv_mfma_kernel<NT, PREC, 4>), grid, dim3(256), lds, st, a);
+// fp32 NHWC -> G8
+__global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off, int cin,
+                                 _Float16* __restrict__ out) {
+    const int cg_n = (cin + 7) >> 3;
+    const size_t plane_px = (size_t)h * w;
+    const size_t total = (size_t)n * cg_n * plane_px;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const size_t px = idx % plane_px;
+    const size_t t = idx / plane_px;
+    const int cg = t % cg_n;
+    const int b = t / cg_n;
+    const float* src = x + ((size_t)b * plane_px + px) * c + c_off + cg * 8;
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = (cg * 8 + j < cin) ? src[j] : 0.f;
+        hi[j] = (_Float16)v;
+        lo[j] = (_Float16)(v - (float)hi[j]);
     }
-    return MPG_OK;
+    _Float16* dst = out + ((((size_t)b * cg_n + cg) * 2) * plane_px + px) * 8;
+    *reinterpret_cast<half8*>(dst) = hi;
+    *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
+}
+
+// G8 -> fp32 NHWC
+__global__ void g8_to_f32_kernel(const _Float16* __restrict__ g, int n, int h, int w, int c, float* __restrict__ y) {
+    const int cg_n = (c + 7) >> 3;
+    const size_t plane_px = (size_t)h * w;
+    const size_t total = (size_t)n * plane_px * c;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const size_t t = idx / c;
+    const size_t px = t % plane_px;
+    const int b = t / plane_px;
+    const _Float16* src = g + ((((size_t)b * cg_n + (ch >> 3)) * 2) * plane_px + px) * 8 + (ch & 7);
+    y[idx] = (float)src[0] + (float)src[plane_px * 8];
+}
+
+struct Shape {
+    int pt, th, ks, r, ni;
+};
+
+// host mirror of Pipe<NT, PREC>
+Shape pipe_shape(int nt, int prec) {
+    Shape s;
+    const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
+    s.pt = nt >= 3 ? 2 : 4;
+    s.th = 4 * s.pt;
+    if (prec == MPG_PREC_F16X3) s.ks = (nt == 4 || nt == 2) ? 1 : 2;
+    else s.ks = (nt == 4 || nt == 2) ? 2 : 4;
+    s.r = nt == 3 ? 3 : 4;
+    s.ni = s.ks * nt * 1024 * npl / 4096;
+    return s;
+}
+
+struct SegShape {
+    int cgc, nchunks, sc, np, ni_img, img_bytes;
+};
+
+// groups per chunk: two when that removes the half-empty k-step of an odd tap count and the
+// double-buffered images still leave room for two workgroups per CU
+SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
+    const Shape ps = pipe_shape(nt, prec);
+    const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
+    const int cg = (cin + 7) / 8;
+    const int px = (ps.th + kh - 1) * (TW + kw - 1);
+    const int np = (px + 63) & ~63;
+    const int ring = ps.r * ps.ks * nt * 1024 * npl;
+    SegShape s;
+    s.np = np;
+    s.cgc = 1;
+    if (cg >= 2 && ((kh * kw) & 1)) {
+        const int img2 = ((2 * 2 * (np / 64) + 3) & ~3) * 1024;
+        if (TAPOFF_BYTES + 2 * img2 + ring <= 80 * 1024) s.cgc = 2;
+    }
+    const int pieces = s.cgc * 2 * (np / 64);
+    s.ni_img = (pieces + 3) / 4;
+    s.img_bytes = s.ni_img * 4 * 1024;
+    s.nchunks = (cg + s.cgc - 1) / s.cgc;
+    const int ksteps = (kh * kw * s.cgc + 1) / 2;
+    s.sc = (ksteps + ps.ks - 1) / ps.ks;
+    return s;
+}
+
+template <int NT, int PREC>
+void launch_one(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, PREC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_mfma_kernel<NT, PREC>), grid, dim3(256), lds, st, a);
 }
 
 template <int PREC>
-int launch_nt(int nt, int ks, dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+void launch_nt(int nt, dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
     switch (nt) {
-        case 1: return launch_ks<1, PREC>(ks, grid, lds, st, a);
-        case 2: return launch_ks<2, PREC>(ks, grid, lds, st, a);
-        case 3: return launch_ks<3, PREC>(ks, grid, lds, st, a);
-        default: return launch_ks<4, PREC>(ks, grid, lds, st, a);
+        case 1: launch_one<1, PREC>(grid, lds, st, a); break;
+        case 2: launch_one<2, PREC>(grid, lds, st, a); break;
+        case 3: launch_one<3, PREC>(grid, lds, st, a); break;
+        default: launch_one<4, PREC>(grid, lds, st, a); break;
     }
 }
 
-int default_ks(int prec, int ks) {
-    if (ks == 2 || ks == 4) return ks;
-    return prec == MPG_PREC_F16X3 ? 2 : 4;
-}
-
-int default_kc(int prec, int kc_max) {
-    if (kc_max == 8 || kc_max == 16 || kc_max == 24 || kc_max == 32) return kc_max;
-    return prec == MPG_PREC_F16X3 ? 16 : 32;
+// 256 zero bytes per device: the DMA source of out-of-image halo pixels (allocated on first use,
+// outside any stream capture; the launch functions themselves never allocate afterwards)
+const char* zero_buffer() {
+    static char* per_dev[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!per_dev[dev]) {
+        char* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+        per_dev[dev] = p;
+    }
+    return per_dev[dev];
 }
 
 }  // namespace
 
-extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec, int kc_max, int ks) {
-    if (kh < 1 || kw < 1 || cin < 1 || cout < 1 || cout > 128) return 0;
-    ks = default_ks(prec, ks);
-    const mpg::SegPlan p = mpg::make_plan(kh, kw, cin, default_kc(prec, kc_max), ks);
-    const int nt = (cout + 31) / 32;
-    const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
-    return (size_t)p.nchunks * p.sc * ks * nt * 1024 * npl;
+extern "C" size_t mpg_g8_bytes(int n, int h, int w, int c) {
+    if (n < 1 || h < 1 || w < 1 || c < 1) return 0;
+    return (size_t)n * ((c + 7) / 8) * 2 * h * w * 16;
 }
 
-extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw,
-                                     int w_cin_total, int w_c_off, int cin, int cout, float wscale,
-                                     const float* cout_scale, int prec, int kc_max, int ks, void* out,
-                                     size_t out_bytes) {
+extern "C" int mpg_f32_to_g8(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
+                             void* out) {
+    MPG_REQUIRE(x && out, "mpg_f32_to_g8: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && c_off >= 0 && cin >= 1 && c_off + cin <= c, "mpg_f32_to_g8: bad shape");
+    const size_t total = (size_t)n * ((cin + 7) / 8) * h * w;
+    hipLaunchKernelGGL(f32_to_g8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, h,
+                       w, c, c_off, cin, (_Float16*)out);
+    MPG_LAUNCH_CHECK("f32_to_g8_kernel");
+}
+
+extern "C" int mpg_g8_to_f32(mpg_stream_t stream, const void* g8, int n, int h, int w, int c, float* y) {
+    MPG_REQUIRE(g8 && y, "mpg_g8_to_f32: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "mpg_g8_to_f32: bad shape");
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(g8_to_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const _Float16*)g8, n, h, w, c, y);
+    MPG_LAUNCH_CHECK("g8_to_f32_kernel");
+}
+
+extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec) {
+    if (kh < 1 || kw < 1 || kh > 7 || kw > 7 || cin < 1 || cout < 1 || cout > 128) return 0;
+    if (prec != MPG_PREC_F16X1 && prec != MPG_PREC_F16X3) return 0;
+    const int nt = (cout + 31) / 32;
+    const Shape ps = pipe_shape(nt, prec);
+    const SegShape ss = seg_shape(kh, kw, cin, nt, prec);
+    const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
+    return (size_t)ss.nchunks * ss.sc * ps.ks * nt * 1024 * npl;
+}
+
+extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw, int w_cin_total,
+                                     int w_c_off, int cin, int cout, float wscale, const float* cout_scale, int prec,
+                                     void* out, size_t out_bytes) {
     MPG_REQUIRE(w_hwio && out, "mpg_conv_pack_weights: null pointer");
     MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3, "mpg_conv_pack_weights: bad prec %d", prec);
     MPG_REQUIRE(kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7, "mpg_conv_pack_weights: kernel %dx%d unsupported", kh, kw);
     MPG_REQUIRE(cin >= 1 && w_c_off >= 0 && w_c_off + cin <= w_cin_total, "mpg_conv_pack_weights: channel range");
     MPG_REQUIRE(cout >= 1 && cout <= 128, "mpg_conv_pack_weights: cout %d not in 1..128", cout);
-    const size_t need = mpg_conv_pack_size(kh, kw, cin, cout, prec, kc_max, ks);
+    const size_t need = mpg_conv_pack_size(kh, kw, cin, cout, prec);
     MPG_REQUIRE(out_bytes >= need, "mpg_conv_pack_weights: out buffer %zu < %zu", out_bytes, need);
-    ks = default_ks(prec, ks);
-    const mpg::SegPlan p = mpg::make_plan(kh, kw, cin, default_kc(prec, kc_max), ks);
     const int nt = (cout + 31) / 32;
+    const Shape ps = pipe_shape(nt, prec);
+    const SegShape ss = seg_shape(kh, kw, cin, nt, prec);
     const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
-    const long total = (long)p.nchunks * p.sc * ks * nt * 512;
+    const long total = (long)ss.nchunks * ss.sc * ps.ks * nt * 512;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, kh, kw,
-                       w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ks, npl, p.kc, p.g, p.nchunks, p.sc,
+                       w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ps.ks, npl, ss.cgc, ss.nchunks, ss.sc,
                        (_Float16*)out);
     MPG_LAUNCH_CHECK("pack_weights_kernel");
 }
@@ -387,63 +550,62 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(d->n >= 1 && d->h >= 1 && d->w >= 1, "mpg_conv2d_fused: bad shape %d x %d x %d", d->n, d->h, d->w);
     MPG_REQUIRE(d->cout >= 1 && d->cout <= 128, "mpg_conv2d_fused: cout %d not in 1..128", d->cout);
     MPG_REQUIRE(d->nseg >= 1 && d->nseg <= MPG_MAX_SEG, "mpg_conv2d_fused: nseg %d", d->nseg);
-    MPG_REQUIRE(d->y != nullptr, "mpg_conv2d_fused: null output");
+    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr, "mpg_conv2d_fused: no output requested");
     MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3, "mpg_conv2d_fused: bad prec %d", d->prec);
     MPG_REQUIRE(d->act >= MPG_ACT_NONE && d->act <= MPG_ACT_TANH, "mpg_conv2d_fused: bad act %d", d->act);
-    const int ks = default_ks(d->prec, d->ks);
-    const int kc_max = default_kc(d->prec, d->kc_max);
-    const int npl = d->prec == MPG_PREC_F16X3 ? 2 : 1;
     const int nt = (d->cout + 31) / 32;
+    const Shape ps = pipe_shape(nt, d->prec);
+    const int npl = d->prec == MPG_PREC_F16X3 ? 2 : 1;
 
     ConvArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cout = d->cout; a.nseg = d->nseg;
-    int khm = 1, kwm = 1;
+    int max_img = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const mpg_conv_seg& g = d->seg[s];
         MPG_REQUIRE(g.x && g.wpack, "mpg_conv2d_fused: segment %d null pointer", s);
         MPG_REQUIRE(g.kh >= 1 && g.kh <= 7 && g.kw >= 1 && g.kw <= 7, "mpg_conv2d_fused: segment %d kernel %dx%d", s, g.kh, g.kw);
-        MPG_REQUIRE(g.cin >= 1 && g.c_off >= 0 && g.c_off + g.cin <= g.cin_stride, "mpg_conv2d_fused: segment %d channel range", s);
+        MPG_REQUIRE(g.cin >= 1 && g.g_off >= 0 && g.g_off + (g.cin + 7) / 8 <= g.cgroups,
+                    "mpg_conv2d_fused: segment %d channel-group range", s);
         MPG_REQUIRE(g.up_log2 >= 0 && g.up_log2 <= 4, "mpg_conv2d_fused: segment %d up_log2 %d", s, g.up_log2);
         MPG_REQUIRE((d->h % (1 << g.up_log2)) == 0 && (d->w % (1 << g.up_log2)) == 0,
                     "mpg_conv2d_fused: segment %d: %dx%d not divisible by upsample %d", s, d->h, d->w, 1 << g.up_log2);
-        khm = g.kh > khm ? g.kh : khm;
-        kwm = g.kw > kwm ? g.kw : kwm;
-    }
-    a.pad_t = (khm - 1) / 2;
-    a.pad_l = (kwm - 1) / 2;
-    a.halo_h = TH + khm - 1;
-    a.halo_w = TW + kwm - 1;
-    int max_ps = 0;
-    for (int s = 0; s < d->nseg; ++s) {
-        const mpg_conv_seg& g = d->seg[s];
-        const mpg::SegPlan p = mpg::make_plan(g.kh, g.kw, g.cin, kc_max, ks);
-        MPG_REQUIRE(p.sc * ks * 2 <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
+        MPG_REQUIRE((((uintptr_t)g.x) & 15) == 0 && (((uintptr_t)g.wpack) & 15) == 0, "mpg_conv2d_fused: segment %d misaligned", s);
+        const SegShape ss = seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
+        MPG_REQUIRE(ss.sc * ps.ks * 2 <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
         SegArgs& o = a.seg[s];
-        o.x = g.x; o.w = (const char*)g.wpack;
-        o.cin = g.cin; o.cin_stride = g.cin_stride; o.c_off = g.c_off; o.kh = g.kh; o.kw = g.kw; o.up = g.up_log2;
-        o.kc = p.kc; o.g = p.g; o.nchunks = p.nchunks; o.sc = p.sc; o.ps = p.ps;
-        o.oy = a.pad_t - (g.kh - 1) / 2;
-        o.ox = a.pad_l - (g.kw - 1) / 2;
+        o.x = (const char*)g.x; o.w = (const char*)g.wpack;
+        o.cg_seg = (g.cin + 7) / 8; o.cg_total = g.cgroups; o.g_off = g.g_off;
+        o.kh = g.kh; o.kw = g.kw; o.up = g.up_log2;
+        o.cgc = ss.cgc; o.nchunks = ss.nchunks; o.sc = ss.sc;
+        o.ih = ps.th + g.kh - 1; o.iw = TW + g.kw - 1;
+        o.pt = (g.kh - 1) / 2; o.pl = (g.kw - 1) / 2;
         o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2;
-        o.vec4 = ((g.cin_stride & 3) == 0 && (g.c_off & 3) == 0 && (((uintptr_t)g.x) & 15) == 0) ? 1 : 0;
-        max_ps = p.ps > max_ps ? p.ps : max_ps;
+        o.np = ss.np; o.ni_img = ss.ni_img;
+        max_img = ss.img_bytes > max_img ? ss.img_bytes : max_img;
     }
     for (int s = d->nseg; s < MPG_MAX_SEG; ++s) a.seg[s] = a.seg[0];
     a.bias = d->bias; a.act = d->act; a.leak = d->leak; a.pn = d->pixel_norm; a.pn_eps = d->pn_eps;
     a.post_add = d->post_add; a.pa_stride = d->post_add_stride; a.pa_coff = d->post_add_coff;
     MPG_REQUIRE(!d->post_add || d->post_add_coff + d->cout <= d->post_add_stride, "mpg_conv2d_fused: post_add channel range");
     a.y = d->y;
-    a.in_plane = ((a.halo_h * a.halo_w * max_ps) + 15) & ~15;
+    a.y_g8 = (char*)d->y_g8;
+    MPG_REQUIRE((((uintptr_t)d->y) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0, "mpg_conv2d_fused: misaligned output");
+    a.zeros = zero_buffer();
+    MPG_REQUIRE(a.zeros != nullptr, "mpg_conv2d_fused: could not allocate the zero page");
+    a.img_bytes = max_img;
     a.tiles_x = (d->w + TW - 1) / TW;
-    a.tiles_y = (d->h + TH - 1) / TH;
+    a.tiles_y = (d->h + ps.th - 1) / ps.th;
+    a.dbg = d->reserved;
     const long nblk = (long)d->n * a.tiles_x * a.tiles_y;
     MPG_REQUIRE(nblk < (1L << 31), "mpg_conv2d_fused: grid too large");
-    const size_t lds = TAPOFF_BYTES + (size_t)a.in_plane * npl + 2 * (size_t)ks * nt * 1024 * npl;
+    const size_t lds_loop = TAPOFF_BYTES + 2 * (size_t)max_img + (size_t)ps.r * ps.ks * nt * 1024 * npl;
+    const size_t lds_epi = TAPOFF_BYTES + (size_t)4 * 32 * (nt * 32 + 4) * sizeof(float);
+    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_fused: LDS budget %zu exceeds 160 KiB", lds);
     const dim3 grid((unsigned)nblk);
     if (d->prec == MPG_PREC_F16X3)
-        launch_nt<3>(nt, ks, grid, lds, (hipStream_t)stream, a);
+        launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);
     else
-        launch_nt<1>(nt, ks, grid, lds, (hipStream_t)stream, a);
+        launch_nt<1>(nt, grid, lds, (hipStream_t)stream, a);
     MPG_LAUNCH_CHECK("conv_mfma_kernel");
 }

@@ -57,6 +57,7 @@ inline int pick_kc(int cin, int kc_max) {
 
 inline SegPlan make_plan(int kh, int kw, int cin, int kc_max, int ks) {
     SegPlan p;
+    if (kh == 1 && kw == 1) kc_max = 32;   // no halo: a 256-pixel image, the widest chunk always fits
     p.kc = pick_kc(cin, kc_max);
     p.g = p.kc / 8;
     const int cin8 = (cin + 7) & ~7;

@@ -44,8 +44,7 @@ class Generator(object):
     """One generator network: private graph + session.  Call with device tensors
     x [N,h,w,C] (and y [N,H,W] for the later 8x generators); returns [N,H,W]."""
 
-    def __init__(self, kind, cfg, params=None, prec=ops.DEFAULT_PREC, device="cuda:0", seed=777, kc_max=0, ks=0,
-                 prec_map=None):
+    def __init__(self, kind, cfg, params=None, prec=ops.DEFAULT_PREC, device="cuda:0", seed=777, prec_map=None):
         self.kind, self.cfg = kind, dict(cfg)
         prev = G.get_default_graph()
         self.graph = G.reset_default_graph()
@@ -79,7 +78,7 @@ class Generator(object):
         finally:
             G._default_graph[0] = prev
         self.sess = Session(device=device, prec=prec, graph=self.graph,
-                            variables=VariableStore(device, seed=seed), kc_max=kc_max, ks=ks, prec_map=prec_map)
+                            variables=VariableStore(device, seed=seed), prec_map=prec_map)
         if params is not None:
             self.sess.vars.load(params)
         self.sess.vars.ensure(self.graph)

@@ -32,17 +32,56 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+class G8(object):
+    """A "G8" activation tensor (include/mpgan.h): [N][ceil(C/8)][2 planes hi, lo][H][W][8 x fp16]."""
+
+    __slots__ = ("buf", "n", "h", "w", "c")
+
+    def __init__(self, buf, n, h, w, c):
+        self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+
+    @property
+    def groups(self):
+        return (self.c + 7) // 8
+
+    @staticmethod
+    def empty(n, h, w, c, device):
+        buf = torch.empty((n, (c + 7) // 8, 2, h, w, 8), dtype=torch.float16, device=device)
+        return G8(buf, n, h, w, c)
+
+
+def to_g8(x, c_off=0, cin=None):
+    """fp32 NHWC x[..., c_off:c_off+cin] -> G8 (mpg_f32_to_g8)"""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    if x.dim() != 4:
+        raise _lib.MpgError("to_g8: expected NHWC, got %s" % (tuple(x.shape),))
+    n, h, w, c = x.shape
+    cin = c - c_off if cin is None else cin
+    g = G8.empty(n, h, w, cin, x.device)
+    if x.numel():
+        _lib.check(lib.mpg_f32_to_g8(_stream(), _ptr(x), n, h, w, c, c_off, cin, _ptr(g.buf)), "mpg_f32_to_g8")
+    return g
+
+
+def from_g8(g):
+    """G8 -> fp32 NHWC (mpg_g8_to_f32)"""
+    lib = _lib.load()
+    y = torch.empty((g.n, g.h, g.w, g.c), dtype=torch.float32, device=g.buf.device)
+    _lib.check(lib.mpg_g8_to_f32(_stream(), _ptr(g.buf), g.n, g.h, g.w, g.c, _ptr(y)), "mpg_g8_to_f32")
+    return y
+
+
 class PackedWeights(object):
     """Weights of one conv segment in MFMA fragment order (mpg_conv_pack_weights)."""
 
-    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec", "kc_max", "ks")
+    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec")
 
-    def __init__(self, buf, kh, kw, cin, cout, prec, kc_max, ks):
-        self.buf, self.kh, self.kw, self.cin, self.cout = buf, kh, kw, cin, cout
-        self.prec, self.kc_max, self.ks = prec, kc_max, ks
+    def __init__(self, buf, kh, kw, cin, cout, prec):
+        self.buf, self.kh, self.kw, self.cin, self.cout, self.prec = buf, kh, kw, cin, cout, prec
 
 
-def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, prec=DEFAULT_PREC, kc_max=0, ks=0):
+def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, prec=DEFAULT_PREC):
     """Pack W[kh,kw,cin_total,cout] channels [c_off, c_off+cin) times wscale
     (GAN.weight_variable, GAN.py:664-668) times an optional per-channel scale
     (folded batch norm, GAN.py:110)."""
@@ -50,51 +89,58 @@ def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, pr
     w = _dev(w_hwio, "w_hwio")
     kh, kw, cin_total, cout = w.shape
     cin = cin_total - c_off if cin is None else cin
-    nbytes = lib.mpg_conv_pack_size(kh, kw, cin, cout, prec, kc_max, ks)
+    nbytes = lib.mpg_conv_pack_size(kh, kw, cin, cout, prec)
     if nbytes == 0:
         raise _lib.MpgError("mpg_conv_pack_size: unsupported conv %dx%d %d->%d" % (kh, kw, cin, cout))
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     cs = _dev(cout_scale, "cout_scale") if cout_scale is not None else None
     rc = lib.mpg_conv_pack_weights(_stream(), _ptr(w), kh, kw, cin_total, c_off, cin, cout, float(wscale), _ptr(cs),
-                                   prec, kc_max, ks, _ptr(buf), nbytes)
+                                   prec, _ptr(buf), nbytes)
     _lib.check(rc, "mpg_conv_pack_weights")
-    return PackedWeights(buf, kh, kw, cin, cout, prec, kc_max, ks)
+    return PackedWeights(buf, kh, kw, cin, cout, prec)
 
 
 class Segment(object):
-    """One K-slice of a fused convolution: source tensor, channel window, packed weights."""
+    """One K-slice of a fused convolution: G8 source (an fp32 NHWC tensor is converted on the
+    fly), first channel group consumed, packed weights, fused nearest upsample."""
 
-    __slots__ = ("x", "packed", "c_off", "up_log2")
+    __slots__ = ("x", "packed", "g_off", "up_log2")
 
     def __init__(self, x, packed, c_off=0, up_log2=0):
-        self.x, self.packed, self.c_off, self.up_log2 = x, packed, c_off, up_log2
+        if isinstance(x, torch.Tensor):
+            x = to_g8(x, c_off, packed.cin)
+            c_off = 0
+        if c_off % 8:
+            raise _lib.MpgError("Segment: channel offset %d of a G8 source is not a multiple of 8" % c_off)
+        self.x, self.packed, self.g_off, self.up_log2 = x, packed, c_off // 8, up_log2
 
 
 def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=False, pn_eps=1e-8,
-                 post_add=None, post_add_coff=0, out=None):
-    """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h."""
+                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, reserved=0):
+    """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h.
+    Returns the fp32 NHWC tensor, the G8 tensor, or (fp32, G8) when both are requested."""
     lib = _lib.load()
     if not 1 <= len(segments) <= _lib.MAX_SEG:
         raise _lib.MpgError("conv2d_fused: %d segments (1..%d supported)" % (len(segments), _lib.MAX_SEG))
     p0 = segments[0].packed
     h, w = out_hw
-    n = segments[0].x.shape[0]
+    n = segments[0].x.n
+    dev = segments[0].x.buf.device
     d = _lib.ConvDesc()
     d.n, d.h, d.w, d.cout, d.nseg = n, h, w, p0.cout, len(segments)
     for i, s in enumerate(segments):
-        x = _dev(s.x, "segment %d input" % i)
-        pk = s.packed
-        if (pk.cout, pk.prec, pk.kc_max, pk.ks) != (p0.cout, p0.prec, p0.kc_max, p0.ks):
-            raise _lib.MpgError("conv2d_fused: segments packed with different cout/prec/tuning")
-        if x.dim() != 4 or x.shape[0] != n or x.shape[1] << s.up_log2 != h or x.shape[2] << s.up_log2 != w:
-            raise _lib.MpgError("conv2d_fused: segment %d input %s does not match output %dx%dx%d (up 2^%d)"
-                                % (i, tuple(x.shape), n, h, w, s.up_log2))
-        if s.c_off + pk.cin > x.shape[3]:
+        g8, pk = s.x, s.packed
+        if (pk.cout, pk.prec) != (p0.cout, p0.prec):
+            raise _lib.MpgError("conv2d_fused: segments packed with different cout/prec")
+        if g8.n != n or g8.h << s.up_log2 != h or g8.w << s.up_log2 != w:
+            raise _lib.MpgError("conv2d_fused: segment %d input %dx%dx%d does not match output %dx%dx%d (up 2^%d)"
+                                % (i, g8.n, g8.h, g8.w, n, h, w, s.up_log2))
+        if s.g_off * 8 + pk.cin > g8.c:
             raise _lib.MpgError("conv2d_fused: segment %d channel window [%d,%d) exceeds %d"
-                                % (i, s.c_off, s.c_off + pk.cin, x.shape[3]))
+                                % (i, s.g_off * 8, s.g_off * 8 + pk.cin, g8.c))
         g = d.seg[i]
-        g.x, g.wpack = x.data_ptr(), pk.buf.data_ptr()
-        g.cin, g.cin_stride, g.c_off = pk.cin, x.shape[3], s.c_off
+        g.x, g.wpack = g8.buf.data_ptr(), pk.buf.data_ptr()
+        g.cin, g.cgroups, g.g_off = pk.cin, g8.groups, s.g_off
         g.kh, g.kw, g.up_log2 = pk.kh, pk.kw, s.up_log2
     if bias is not None:
         b = _dev(bias, "bias")
@@ -108,16 +154,27 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         if pa.dim() != 4 or tuple(pa.shape[:3]) != (n, h, w) or post_add_coff + p0.cout > pa.shape[3]:
             raise _lib.MpgError("conv2d_fused: post_add %s does not match output" % (tuple(pa.shape),))
         d.post_add, d.post_add_stride, d.post_add_coff = pa.data_ptr(), pa.shape[3], post_add_coff
-    if out is None:
-        out = torch.empty((n, h, w, p0.cout), dtype=torch.float32, device=segments[0].x.device)
-    else:
-        _dev(out, "out")
-        if tuple(out.shape) != (n, h, w, p0.cout):
-            raise _lib.MpgError("conv2d_fused: out has shape %s" % (tuple(out.shape),))
-    d.y = out.data_ptr()
-    d.prec, d.kc_max, d.ks = p0.prec, p0.kc_max, p0.ks
+    y = y8 = None
+    if out is not None:
+        want_f32 = True
+    if want_f32:
+        if out is None:
+            y = torch.empty((n, h, w, p0.cout), dtype=torch.float32, device=dev)
+        else:
+            y = _dev(out, "out")
+            if tuple(y.shape) != (n, h, w, p0.cout):
+                raise _lib.MpgError("conv2d_fused: out has shape %s" % (tuple(y.shape),))
+        d.y = y.data_ptr()
+    if want_g8:
+        y8 = G8.empty(n, h, w, p0.cout, dev)
+        d.y_g8 = y8.buf.data_ptr()
+    if y is None and y8 is None:
+        raise _lib.MpgError("conv2d_fused: no output requested")
+    d.prec, d.reserved = p0.prec, reserved
     _lib.check(lib.mpg_conv2d_fused(_stream(), ctypes.byref(d)), "mpg_conv2d_fused")
-    return out
+    if y is not None and y8 is not None:
+        return y, y8
+    return y if y is not None else y8
 
 
 def conv2d_direct(x, w_hwio, stride=(1, 1), wscale=1.0, cout_scale=None, bias=None, act=None, leak=0.2):

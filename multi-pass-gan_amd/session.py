@@ -100,10 +100,9 @@ class _Plan(object):
 
 
 class Session(object):
-    def __init__(self, device="cuda:0", prec=ops.DEFAULT_PREC, variables=None, graph=None, kc_max=0, ks=0,
-                 prec_map=None):
+    def __init__(self, device="cuda:0", prec=ops.DEFAULT_PREC, variables=None, graph=None, prec_map=None):
         self.device = torch.device(device)
-        self.prec, self.kc_max, self.ks = prec, kc_max, ks
+        self.prec = prec
         # per-launch precision override: [(substring of the first term's weight name, prec), ...]
         self.prec_map = list(prec_map or [])
         self.graph = graph or G.get_default_graph()
@@ -146,7 +145,32 @@ class Session(object):
             env[node.id] = fn(env)
             for nid in plan.free_after[i]:
                 env.pop(nid, None)
-        return env[fetch.id]
+        return self._f32(env, fetch)
+
+    # ------------------------------------------------------------------ tensor formats
+    # A fused convolution can emit fp32 NHWC, the G8 layout its consumers DMA from, or both; its env
+    # entry is a dict {"f32": tensor | None, "g8": G8 | None}.  Every other node holds an fp32 tensor.
+    @staticmethod
+    def _f32(env, node):
+        v = env[node.id]
+        if isinstance(v, dict):
+            if v["f32"] is None:
+                v["f32"] = ops.from_g8(v["g8"])
+            return v["f32"]
+        return v
+
+    @staticmethod
+    def _g8(env, node, c_off, cin):
+        """(G8 tensor, channel offset inside it) holding channels [c_off, c_off+cin) of `node`"""
+        v = env[node.id]
+        if isinstance(v, dict) and v["g8"] is not None and c_off % 8 == 0:
+            return v["g8"], c_off
+        key = ("g8", node.id, c_off, cin)
+        g = env.get(key)
+        if g is None:
+            g = ops.to_g8(Session._f32(env, node), c_off, cin)
+            env[key] = g
+        return g, 0
 
     # ------------------------------------------------------------------ compile
     def _compile(self, fetch):
@@ -168,6 +192,9 @@ class Session(object):
         self._fetch = fetch
         plan = _Plan()
         done = set()
+        fused_steps = []       # (node, run) of every fused convolution
+        need_f32 = {fetch.id}  # nodes somebody reads as fp32 NHWC
+        need_g8 = set()        # fused outputs read by another fused convolution (aligned window)
 
         def single_use(n):
             return len(consumers.get(n.id, [])) == 1 and n is not fetch
@@ -189,8 +216,11 @@ class Session(object):
             fused = self._match_fused(n, single_use)
             if fused is not None:
                 deps, fn = fused
+                fused_steps.append((n, fn))
             else:
                 deps, fn = self._fallback(n, single_use)
+                for d in deps:
+                    need_f32.add(d.id)
             for d in deps:
                 emit(d)
             idx = len(plan.steps)
@@ -199,6 +229,18 @@ class Session(object):
                 plan.last_use[d.id] = idx
 
         emit(fetch)
+        fused_ids = set(n.id for n, _ in fused_steps)
+        for n, fn in fused_steps:
+            for seg in fn.info["segments"]:
+                if seg["src_id"] in fused_ids and seg["c_off"] % 8 == 0:
+                    need_g8.add(seg["src_id"])
+                else:
+                    need_f32.add(seg["src_id"])
+            if fn.info["post_add_id"] is not None:
+                need_f32.add(fn.info["post_add_id"])
+        for n, fn in fused_steps:
+            fn.emit["g8"] = n.id in need_g8
+            fn.emit["f32"] = n.id in need_f32 or n.id not in need_g8
         # variables, placeholders and the fetch stay alive; everything else dies after its last reader
         plan.free_after = [[] for _ in plan.steps]
         keep = set(n.id for n, _ in plan.steps if n.op in ("variable", "placeholder"))
@@ -282,20 +324,28 @@ class Session(object):
             if pat in lead:
                 prec = pr
 
+        emit = {"f32": True, "g8": False}
+
         def run(env, segs=segs, terms=terms, prec=prec):
             seg_objs = []
             for (src, c_off_src, up, term, w_off, cin) in segs:
                 pk = self._packed_for(term, w_off, cin, prec)
-                seg_objs.append(ops.Segment(env[src.id], pk, c_off_src, up))
+                g8, off = self._g8(env, src, c_off_src, cin)
+                seg_objs.append(ops.Segment(g8, pk, off, up))
             bias = self._bias_for(terms)
-            pa = env[post_add.id] if post_add is not None else None
-            return ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
-                                    post_add=pa)
+            pa = self._f32(env, post_add) if post_add is not None else None
+            res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
+                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"])
+            if emit["f32"] and emit["g8"]:
+                return {"f32": res[0], "g8": res[1]}
+            return {"f32": res, "g8": None} if emit["f32"] else {"f32": None, "g8": res}
 
+        run.emit = emit
         run.info = {
             "kind": "conv2d_fused", "cout": cout, "act": act, "pixel_norm": pn, "prec": prec,
             "post_add": post_add.name if post_add is not None else None,
-            "segments": [dict(src=src.name, c_off=c_off_src, cin=cin, up_log2=up, w_off=w_off,
+            "post_add_id": post_add.id if post_add is not None else None,
+            "segments": [dict(src=src.name, src_id=src.id, c_off=c_off_src, cin=cin, up_log2=up, w_off=w_off,
                               kernel=tuple(term.conv.inputs[1].shape[:2]), weight=term.conv.inputs[1].attrs["var"])
                          for (src, c_off_src, up, term, w_off, cin) in segs],
         }
@@ -311,6 +361,8 @@ class Session(object):
                 continue
             info = dict(getattr(fn, "info", {"kind": node.op}))
             info["node"] = node.name
+            if hasattr(fn, "emit"):
+                info["emit"] = dict(fn.emit)
             out.append(info)
         return out
 
@@ -399,13 +451,13 @@ class Session(object):
         return res
 
     def _packed_for(self, term, w_off, cin, prec):
-        key = ("pack", term.conv.id, w_off, cin, prec, self.kc_max, self.ks)
+        key = ("pack", term.conv.id, w_off, cin, prec)
         pk = self._packed.get(key)
         if pk is None:
             w = self.vars.get(term.conv.inputs[1].attrs["var"])
             scale, _ = self._bn_scale_shift(term)
             pk = ops.pack_conv_weights(w, wscale=term.conv.attrs["wscale"], cout_scale=scale, c_off=w_off, cin=cin,
-                                       prec=prec, kc_max=self.kc_max, ks=self.ks)
+                                       prec=prec)
             self._packed[key] = pk
         return pk
 
@@ -426,36 +478,36 @@ class Session(object):
         op = n.op
         if op == "reshape":
             tgt = n.attrs["target"]
-            return [n.inputs[0]], lambda env, i=n.inputs[0], t=tgt: env[i.id].reshape(t)
+            return [n.inputs[0]], lambda env, i=n.inputs[0], t=tgt: self._f32(env, i).reshape(t)
         if op == "concat":
-            return list(n.inputs), lambda env, ins=n.inputs: torch.cat([env[i.id] for i in ins], dim=-1).contiguous()
+            return list(n.inputs), lambda env, ins=n.inputs: torch.cat([self._f32(env, i) for i in ins], dim=-1).contiguous()
         if op == "slice":
             b, s = n.attrs["begin"], n.attrs["size"]
-            return [n.inputs[0]], lambda env, i=n.inputs[0]: env[i.id][..., b:b + s].contiguous()
+            return [n.inputs[0]], lambda env, i=n.inputs[0]: self._f32(env, i)[..., b:b + s].contiguous()
         if op == "slice_flat":
             cnt = n.attrs["count"]
-            return [n.inputs[0]], lambda env, i=n.inputs[0]: env[i.id].reshape(env[i.id].shape[0], -1)[:, :cnt].contiguous()
+            return [n.inputs[0]], lambda env, i=n.inputs[0]: self._f32(env, i).reshape(self._f32(env, i).shape[0], -1)[:, :cnt].contiguous()
         if op == "add":
             a, b = n.inputs
-            return [a, b], lambda env: ops.add_act(env[a.id], env[b.id])
+            return [a, b], lambda env: ops.add_act(self._f32(env, a), self._f32(env, b))
         if op == "act":
             x = n.inputs[0]
             if x.op == "add" and single_use(x):
                 a, b = x.inputs
-                return [a, b], lambda env: ops.add_act(env[a.id], env[b.id], n.attrs["act"], n.attrs.get("leak", 0.2))
+                return [a, b], lambda env: ops.add_act(self._f32(env, a), self._f32(env, b), n.attrs["act"], n.attrs.get("leak", 0.2))
             direct = self._match_direct(n, single_use)
             if direct is not None:
                 return direct
-            return [x], lambda env: ops.add_act(env[x.id], None, n.attrs["act"], n.attrs.get("leak", 0.2))
+            return [x], lambda env: ops.add_act(self._f32(env, x), None, n.attrs["act"], n.attrs.get("leak", 0.2))
         if op == "pixel_norm":
             x = n.inputs[0]
-            return [x], lambda env: ops.pixel_norm(env[x.id], n.attrs["eps"])
+            return [x], lambda env: ops.pixel_norm(self._f32(env, x), n.attrs["eps"])
         if op == "resize":
             x = n.inputs[0]
-            return [x], lambda env: ops.resize_images(env[x.id], n.attrs["oh"], n.attrs["ow"], n.attrs["method"])
+            return [x], lambda env: ops.resize_images(self._f32(env, x), n.attrs["oh"], n.attrs["ow"], n.attrs["method"])
         if op == "avg_pool":
             x = n.inputs[0]
-            return [x], lambda env: ops.avg_pool2(env[x.id])
+            return [x], lambda env: ops.avg_pool2(self._f32(env, x))
         if op in ("conv2d", "bias_add", "batch_norm"):
             direct = self._match_direct(n, single_use)
             if direct is not None:
@@ -496,7 +548,7 @@ class Session(object):
             scale, eff = self._bn_scale_shift(term)
             b = eff.float().contiguous()
             w = self.vars.get(wv.attrs["var"])
-            xin = env[x.id]
+            xin = self._f32(env, x)
             if is_fc:
                 y = ops.conv2d_direct(xin.reshape(xin.shape[0], 1, 1, xin.shape[1]).contiguous(),
                                       w.reshape(1, 1, w.shape[0], w.shape[1]), (1, 1), conv.attrs["wscale"], scale, b,

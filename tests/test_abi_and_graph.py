@@ -22,8 +22,10 @@ def test_library_exports_every_declared_symbol(mpg):
     assert declared == set(_lib.PROTOTYPES)
     assert lib.mpg_version().startswith(b"mpgan-hip")
     # host-side helper: no GPU needed
-    assert lib.mpg_conv_pack_size(5, 5, 128, 128, 1, 0, 0) == 4 * 13 * 4 * 4 * 1024
-    assert lib.mpg_conv_pack_size(5, 5, 128, 200, 1, 0, 0) == 0
+    # 16 chunks of one channel group x 13 one-k-step stages x (4 cout tiles x 1 KiB x hi/lo)
+    assert lib.mpg_conv_pack_size(5, 5, 128, 128, 3) == 16 * 13 * 1 * 4 * 1024 * 2
+    assert lib.mpg_conv_pack_size(5, 5, 128, 200, 3) == 0
+    assert lib.mpg_g8_bytes(2, 16, 32, 11) == 2 * 2 * 2 * 16 * 32 * 16
 
 
 def test_struct_layout_matches_header(mpg):
@@ -31,6 +33,7 @@ def test_struct_layout_matches_header(mpg):
     from mpgan_amd import _lib
     assert ctypes.sizeof(_lib.ConvSeg) == 40
     assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 40 + 64
+    assert _lib.ConvDesc.y_g8.offset == 232 and _lib.ConvDesc.reserved.offset == 244
 
 
 def test_compute_refuses_without_gpu(mpg):
@@ -103,6 +106,9 @@ def test_fusion_plan(mpg):
     g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)
     launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] == "conv2d_fused"]
     assert [e["cout"] for e in launches] == [2, 8, 128, 128, 32, 8, 2, 1]
+    # activations between fused launches travel as G8 only; the fetched tensor is fp32
+    assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True}] * 7
+    assert launches[-1]["emit"] == {"f32": True, "g8": False}
     assert [len(e["segments"]) for e in launches] == [1, 2, 1, 2, 1, 2, 1, 2]
     assert launches[0]["segments"][0]["up_log2"] == 2 and launches[1]["segments"][1]["up_log2"] == 2
     assert all(e["act"] == "relu" for e in launches)

@@ -63,16 +63,36 @@ def test_conv2d_fused_single(gpu_ops, case, prec, tol):
     assert err < tol, err
 
 
-@pytest.mark.parametrize("kc_max,ks", [(8, 2), (16, 4), (24, 2), (32, 4), (32, 2), (16, 2)])
-def test_conv2d_fused_tuning_variants(gpu_ops, kc_max, ks):
-    rng = _rng(kc_max * 10 + ks)
-    x = rng.standard_normal((1, 16, 32, 96)).astype(np.float32)
-    wt = rng.standard_normal((3, 3, 96, 40)).astype(np.float32)
-    ref = O.conv2d_same(x, wt)
-    for prec, tol in ((3, 2e-5), (1, 1.5e-3)):
-        pk = gpu_ops.pack_conv_weights(_t(wt), prec=prec, kc_max=kc_max, ks=ks)
-        y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (16, 32))
-        assert rel_l2(y.cpu().numpy(), ref) < tol
+def test_g8_roundtrip_and_chained_convs(gpu_ops):
+    """fp32 <-> G8 conversion (hi + lo fp16 planes) and two convolutions chained through a G8
+    tensor, the way the session passes activations between fused launches"""
+    rng = _rng(5)
+    x = rng.standard_normal((2, 16, 32, 11)).astype(np.float32)
+    g = gpu_ops.to_g8(_t(x))
+    assert g.groups == 2 and tuple(g.buf.shape) == (2, 2, 2, 16, 32, 8)
+    back = gpu_ops.from_g8(g).cpu().numpy()
+    assert np.abs(back - x).max() <= np.abs(x).max() * 2.0 ** -21
+    win = gpu_ops.from_g8(gpu_ops.to_g8(_t(x), 3, 5)).cpu().numpy()
+    assert np.abs(win - x[..., 3:8]).max() <= np.abs(x).max() * 2.0 ** -21
+    w1 = rng.standard_normal((3, 3, 11, 40)).astype(np.float32)
+    w2 = rng.standard_normal((5, 5, 40, 7)).astype(np.float32)
+    ref1 = O.relu(O.conv2d_same(x, w1))
+    ref2 = O.conv2d_same(ref1, w2)
+    for prec, tol in ((3, 3e-5), (1, 2e-3)):
+        p1 = gpu_ops.pack_conv_weights(_t(w1), prec=prec)
+        p2 = gpu_ops.pack_conv_weights(_t(w2), prec=prec)
+        y1, g1 = gpu_ops.conv2d_fused([gpu_ops.Segment(g, p1)], (16, 32), act="relu", want_f32=True, want_g8=True)
+        assert rel_l2(y1.cpu().numpy(), ref1) < tol
+        assert g1.c == 40 and g1.groups == 5
+        if prec == 3:
+            assert np.abs(gpu_ops.from_g8(g1).cpu().numpy() - y1.cpu().numpy()).max() <= np.abs(ref1).max() * 2.0 ** -21
+        y2 = gpu_ops.conv2d_fused([gpu_ops.Segment(g1, p2)], (16, 32))
+        assert rel_l2(y2.cpu().numpy(), ref2) < tol
+        # aligned channel window of a G8 source: groups 1.. of g1 (channels 8..39)
+        w3 = rng.standard_normal((3, 3, 32, 16)).astype(np.float32)
+        p3 = gpu_ops.pack_conv_weights(_t(w3), prec=prec)
+        y3 = gpu_ops.conv2d_fused([gpu_ops.Segment(g1, p3, c_off=8)], (16, 32))
+        assert rel_l2(y3.cpu().numpy(), O.conv2d_same(ref1[..., 8:40], w3)) < tol
 
 
 def test_conv2d_fused_exact_integers(gpu_ops):
