@@ -42,6 +42,7 @@ struct SegArgs {
     int hs, ws;           // source height / width (h >> up, w >> up)
     int np;               // pixels per image plane, padded to a multiple of 64
     int ni_img;           // image DMA instructions per thread per chunk
+    int sw_hi, sw_lo;     // F16F8: E8M0 scale words (replicated bytes) of the fp8 weight planes
 };
 
 struct ConvArgs {
@@ -55,7 +56,8 @@ struct ConvArgs {
     const float* post_add;
     int pa_stride, pa_coff;
     float* y;             // fp32 NHWC output or null
-    char* y_g8;           // G8 output or null
+    char* y_g8;           // G8 output (planes hi16, lo16) or null
+    char* y_g8c;          // G8 output in the F16F8 flavour (planes hi16, {hi8 | lo8}) or null
     const char* zeros;    // >= 16 zero bytes (source of out-of-image pixels)
     int img_bytes;        // bytes of one LDS image buffer (max over segments)
     int tiles_x, tiles_y;
@@ -88,6 +90,157 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     // lane l of the wave copies 16 bytes from its own `src` to lds_wave_base + 16*l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// fp8 (OCP e4m3) exponents of the activation planes of the F16F8 flavour: hi8 = fp8(v * 2^SA_HI),
+// lo8 = fp8((v - fp16(v)) * 2^SA_LO); the MFMA block scales undo them (E8M0 = 127 - S)
+constexpr int SA_HI = 2;
+constexpr int SA_LO = 13;
+
+__device__ __forceinline__ int pack4_fp8(float v0, float v1, float v2, float v3, float scale) {
+    // saturate to the e4m3 range before converting
+    const float lim = 448.f;
+    v0 = fminf(fmaxf(v0 * scale, -lim), lim);
+    v1 = fminf(fmaxf(v1 * scale, -lim), lim);
+    v2 = fminf(fmaxf(v2 * scale, -lim), lim);
+    v3 = fminf(fmaxf(v3 * scale, -lim), lim);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, w, true);
+}
+
+// plane 1 of the F16F8 flavour for 8 channel values: bytes 0-7 hi8, bytes 8-15 lo8
+__device__ __forceinline__ int4 g8c_plane1(const float v[8]) {
+    float lo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lo[j] = v[j] - (float)(_Float16)v[j];
+    int4 o;
+    o.x = pack4_fp8(v[0], v[1], v[2], v[3], (float)(1 << SA_HI));
+    o.y = pack4_fp8(v[4], v[5], v[6], v[7], (float)(1 << SA_HI));
+    o.z = pack4_fp8(lo[0], lo[1], lo[2], lo[3], (float)(1 << SA_LO));
+    o.w = pack4_fp8(lo[4], lo[5], lo[6], lo[7], (float)(1 << SA_LO));
+    return o;
+}
+
+template <int NT, int PT>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs ap, char* smem, int n, int y0, int x0,
+                                              int wave, int lane) {
+    const auto& a = *ap;
+    const int r = lane & 31;
+    const int hh = lane >> 5;
+    // accumulator element i of n-tile nt: output channel nt*32 + 8*(i>>2) + 4*hh + (i&3), pixel r.
+    constexpr int ROWF = NT * 32 + 4;
+    float* stg = reinterpret_cast<float*>(smem + TAPOFF_BYTES) + wave * (32 * ROWF);
+    const int cg_out = (a.cout + 7) >> 3;
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const int py = y0 + PT * wave + pt;
+        float ss = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (co0 + i < a.cout) b4[i] = a.bias[co0 + i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = mpg::apply_act(acc[pt][nt][4 * q4 + i] + b4[i], a.act, a.leak);
+                    if (co0 + i >= a.cout) v = 0.f;
+                    acc[pt][nt][4 * q4 + i] = v;
+                    ss += v * v;
+                }
+            }
+        if (a.pn) {
+            ss += __shfl_xor(ss, 32);
+            const float sc = rsqrtf(ss / (float)a.cout + a.pn_eps);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[pt][nt][i] *= sc;
+        }
+        // stage this wave's 32 pixels x cout through LDS ([pixel][cout] rows padded by 16 B); the 32
+        // pixels of a tile row are contiguous in every output layout, so all stores are whole runs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<float4*>(stg + r * ROWF + co0) =
+                    make_float4(acc[pt][nt][4 * q4], acc[pt][nt][4 * q4 + 1], acc[pt][nt][4 * q4 + 2], acc[pt][nt][4 * q4 + 3]);
+            }
+        if (py < a.h && !(a.dbg & 2)) {
+            const int npx = min(32, a.w - x0);
+            const size_t pix0 = ((size_t)n * a.h + py) * a.w + x0;
+            if (a.post_add != nullptr) {
+                // add into the staged tile first, so both output formats carry it
+                const float* pa = a.post_add + pix0 * a.pa_stride + a.pa_coff;
+                for (int f = lane; f < npx * a.cout; f += 64) {
+                    const int p = f / a.cout;
+                    const int c = f - p * a.cout;
+                    stg[p * ROWF + c] += pa[(size_t)p * a.pa_stride + c];
+                }
+            }
+            if (a.y != nullptr) {
+                float* dst = a.y + pix0 * a.cout;
+                const int total = npx * a.cout;
+                if ((a.cout & 3) == 0) {
+                    for (int f = lane * 4; f < total; f += 256) {
+                        const int p = f / a.cout;
+                        const int c = f - p * a.cout;
+                        *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(stg + p * ROWF + c);
+                    }
+                } else {
+                    for (int f = lane; f < total; f += 64) {
+                        const int p = f / a.cout;
+                        dst[f] = stg[p * ROWF + (f - p * a.cout)];
+                    }
+                }
+            }
+            if (a.y_g8 != nullptr) {
+                // lanes 0-31 write the hi plane, lanes 32-63 the lo plane of pixel r: 512-byte runs
+                const size_t plane_px = (size_t)a.h * a.w;
+                if (r < npx) {
+                    for (int cg = 0; cg < cg_out; ++cg) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        half8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const _Float16 hi = (_Float16)v[j];
+                            o[j] = hh ? (_Float16)(v[j] - (float)hi) : hi;
+                        }
+                        char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                        *reinterpret_cast<half8*>(dst) = o;
+                    }
+                }
+            }
+            if (a.y_g8c != nullptr) {
+                // lanes 0-31: hi16 plane; lanes 32-63: the {hi8 | lo8} plane
+                const size_t plane_px = (size_t)a.h * a.w;
+                if (r < npx) {
+                    for (int cg = 0; cg < cg_out; ++cg) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
+                        const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
+                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                        char* dst = a.y_g8c + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                        if (hh) {
+                            *reinterpret_cast<int4*>(dst) = g8c_plane1(v);
+                        } else {
+                            half8 o;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
+                            *reinterpret_cast<half8*>(dst) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int NT, int PREC>
@@ -235,100 +388,225 @@ __global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const
         __syncthreads();
     }
 
-    // ---------------- epilogue: bias, activation, pixel norm, post add, stores ----------------
-    // accumulator element i of n-tile nt: output channel nt*32 + 8*(i>>2) + 4*hh + (i&3), pixel r.
-    constexpr int ROWF = NT * 32 + 4;
-    float* stg = reinterpret_cast<float*>(smem + TAPOFF_BYTES) + wave * (32 * ROWF);
-    const int cg_out = (a.cout + 7) >> 3;
+    conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MPG_PREC_F16F8: one fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and
+// a_hi*w_lo on the block-scaled fp8 path (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, K = 64
+// per instruction at twice the fp16 rate per K).  The corrections only need ~4 bits: together the
+// three products are accurate to ~2^-15 per operand instead of fp16's 2^-11.
+// One workgroup = WAVES waves = 16 tile rows x 32 pixels; a weight stage is one macro-step of 8 taps
+// (K = 64): [4 fp16 k-steps][w_hi8][w_lo8]; chunks are single channel groups.
+// ---------------------------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+template <int NT>
+struct Pipe8 {
+    static constexpr int WAVES = (NT == 4) ? 8 : 4;
+    static constexpr int PT = 16 / WAVES;                  // tile rows per wave
+    static constexpr int TH = 16;
+    static constexpr int WF16 = 4 * NT * 1024;             // four fp16 k-steps
+    static constexpr int WF8 = NT * 2048;                  // one fp8 plane: NT x 64 lanes x 32 B
+    static constexpr int WSTAGE = WF16 + 2 * WF8;          // 8 * NT KiB
+    static constexpr int R = 3;
+    static constexpr int D = R - 1;
+    static constexpr int NI = WSTAGE / (WAVES * 1024);
+    static_assert(WSTAGE % (WAVES * 1024) == 0, "stage must be a whole number of per-wave pieces");
+};
+
+template <int NT>
+__global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(const ConvArgs a_unused) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    const auto& a = *ap;
+    using P = Pipe8<NT>;
+    constexpr int WAVES = P::WAVES, PT = P::PT, TH = P::TH, WF16 = P::WF16, WF8 = P::WF8, WSTAGE = P::WSTAGE;
+    constexpr int NI = P::NI, R = P::R, D = P::D, THREADS = WAVES * 64;
+
+    int* tapoff = reinterpret_cast<int*>(smem);
+    char* img_lds = smem + TAPOFF_BYTES;
+    char* w_lds = img_lds + 2 * a.img_bytes;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int r = lane & 31;
+    const int hh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
+    const int tx = bid % a.tiles_x;
+    const int t2 = bid / a.tiles_x;
+    const int ty = t2 % a.tiles_y;
+    const int n = t2 / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    f32x16 acc[PT][NT];
 #pragma unroll
-    for (int pt = 0; pt < PT; ++pt) {
-        const int py = y0 + PT * wave + pt;
-        float ss = 0.f;
+    for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
-                float b4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr) {
+            for (int i = 0; i < 16; ++i) acc[pt][nt][i] = 0.f;
+
+    const int sa_hi = (127 - SA_HI) * 0x01010101;
+    const int sa_lo = (127 - SA_LO) * 0x01010101;
+
+    for (int s = 0; s < ((a.dbg & 1) ? 0 : a.nseg); ++s) {
+        const auto& sg = ap->seg[s];
+        const int T = sg.kh * sg.kw;
+        const int plane_b = sg.np * 16;
+        const int ppg = sg.np >> 6;
+
+        for (int q = tid; q < sg.sc * 8; q += THREADS) {
+            int off = 0;
+            if (q < T) {
+                const int dy = q / sg.kw;
+                const int dx = q - dy * sg.kw;
+                off = (dy * sg.iw + dx) * 16;
+            }
+            tapoff[q] = off;
+        }
+        int pixb[PT];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (co0 + i < a.cout) b4[i] = a.bias[co0 + i];
+        for (int pt = 0; pt < PT; ++pt) pixb[pt] = ((PT * wave + pt) * sg.iw + r) * 16;
+
+        const size_t plane_px = (size_t)sg.hs * sg.ws;
+        auto dma_image = [&](int chunk) {
+            char* buf = img_lds + (chunk & 1) * a.img_bytes;
+            for (int i = 0; i < sg.ni_img; ++i) {
+                const int pc = WAVES * i + wave_u;
+                const int pl = pc / ppg;                       // plane: 0 hi16, 1 {hi8|lo8}
+                const int p = (pc - pl * ppg) * 64 + lane;
+                const int hy = p / sg.iw;
+                const int hx = p - hy * sg.iw;
+                const int yy = y0 - sg.pt + hy;
+                const int xx = x0 - sg.pl + hx;
+                const char* src = a.zeros;
+                if (pl < 2 && chunk < sg.cg_seg && hy < sg.ih && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w)
+                    src = sg.x + ((((size_t)n * sg.cg_total + sg.g_off + chunk) * 2 + pl) * plane_px +
+                                  (size_t)(yy >> sg.up) * sg.ws + (xx >> sg.up)) * 16;
+                dma16(src, buf + pc * 1024);
+            }
+        };
+        const int total_stages = sg.nchunks * sg.sc;
+        auto dma_stage = [&](int stage) {
+            const int sidx = stage < total_stages ? stage : total_stages - 1;
+            const char* src = sg.w + (size_t)sidx * WSTAGE + tid * 16;
+            char* dst = w_lds + (stage % R) * WSTAGE + wave_u * 1024;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dma16(src + i * (THREADS * 16), dst + i * (THREADS * 16));
+        };
+
+        dma_image(0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) dma_stage(d);
+
+        for (int ch = 0; ch < sg.nchunks; ++ch) {
+            if (sg.sc < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* img = img_lds + (ch & 1) * a.img_bytes;
+            for (int st = 0; st < sg.sc; ++st) {
+                const int gst = ch * sg.sc + st;
+                wait_dma_and_barrier<(D - 1) * NI>();
+                if (st == 0 && ch + 1 < sg.nchunks) dma_image(ch + 1);
+                dma_stage(gst + D);
+                const char* wb = w_lds + (gst % R) * WSTAGE;
+                const int tap0 = st * 8;
+                // ---- main product: fp16, two taps per k-step; k-steps past the last tap are skipped ----
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (tap0 + 2 * j < T) {
+                        const int toff = tapoff[tap0 + 2 * j + hh];
+                        half8 b_hi[PT];
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) b_hi[pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + toff);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                            for (int pt = 0; pt < PT; ++pt)
+                                acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[pt], acc[pt][nt], 0, 0, 0);
+                        }
+                    }
                 }
+                // ---- corrections: lane (pixel r, half hh) holds taps tap0 + 4*hh + {0..3} x 8 channels ----
+                v8i b8_hi[PT], b8_lo[PT];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = mpg::apply_act(acc[pt][nt][4 * q4 + i] + b4[i], a.act, a.leak);
-                    if (co0 + i >= a.cout) v = 0.f;
-                    acc[pt][nt][4 * q4 + i] = v;
-                    ss += v * v;
-                }
-            }
-        if (a.pn) {
-            ss += __shfl_xor(ss, 32);
-            const float sc = rsqrtf(ss / (float)a.cout + a.pn_eps);
+                    const int toff = tapoff[tap0 + 4 * hh + i];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[pt][nt][i] *= sc;
-        }
-        // stage this wave's 32 pixels x cout through LDS ([pixel][cout] rows padded by 16 B); the 32
-        // pixels of a tile row are contiguous in every output layout, so all stores are whole runs
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int co0 = nt * 32 + 8 * q4 + 4 * hh;
-                *reinterpret_cast<float4*>(stg + r * ROWF + co0) =
-                    make_float4(acc[pt][nt][4 * q4], acc[pt][nt][4 * q4 + 1], acc[pt][nt][4 * q4 + 2], acc[pt][nt][4 * q4 + 3]);
-            }
-        if (py < a.h && !(a.dbg & 2)) {
-            const int npx = min(32, a.w - x0);
-            const size_t pix0 = ((size_t)n * a.h + py) * a.w + x0;
-            if (a.post_add != nullptr) {
-                // add into the staged tile first, so both output formats carry it
-                const float* pa = a.post_add + pix0 * a.pa_stride + a.pa_coff;
-                for (int f = lane; f < npx * a.cout; f += 64) {
-                    const int p = f / a.cout;
-                    const int c = f - p * a.cout;
-                    stg[p * ROWF + c] += pa[(size_t)p * a.pa_stride + c];
-                }
-            }
-            if (a.y != nullptr) {
-                float* dst = a.y + pix0 * a.cout;
-                const int total = npx * a.cout;
-                if ((a.cout & 3) == 0) {
-                    for (int f = lane * 4; f < total; f += 256) {
-                        const int p = f / a.cout;
-                        const int c = f - p * a.cout;
-                        *reinterpret_cast<float4*>(dst + f) = *reinterpret_cast<const float4*>(stg + p * ROWF + c);
-                    }
-                } else {
-                    for (int f = lane; f < total; f += 64) {
-                        const int p = f / a.cout;
-                        dst[f] = stg[p * ROWF + (f - p * a.cout)];
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const int4 v = *reinterpret_cast<const int4*>(img + plane_b + pixb[pt] + toff);
+                        b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
+                        b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
                     }
                 }
-            }
-            if (a.y_g8 != nullptr) {
-                // lanes 0-31 write the hi plane, lanes 32-63 the lo plane of pixel r: 512-byte runs
-                const size_t plane_px = (size_t)a.h * a.w;
-                if (r < npx) {
-                    for (int cg = 0; cg < cg_out; ++cg) {
-                        const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
-                        const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
-                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        half8 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const _Float16 hi = (_Float16)v[j];
-                            o[j] = hh ? (_Float16)(v[j] - (float)hi) : hi;
-                        }
-                        char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
-                        *reinterpret_cast<half8*>(dst) = o;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const v8i w8_hi = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
+                    const v8i w8_lo = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
+                                                                                   sg.sw_hi, 0, sa_lo);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_lo, b8_hi[pt], acc[pt][nt], 0, 0, 0,
+                                                                                   sg.sw_lo, 0, sa_hi);
                     }
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
+}
+
+// F16F8 weight image: per (chunk = channel group, macro-step of 8 taps):
+//   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][64 lanes][32 x fp8 hi]  |  [NT][64 lanes][32 x fp8 lo]
+__global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
+                                       int cin, int cout, float wscale, const float* __restrict__ cscale,
+                                       int NT, int nchunks, int sc, float s_hi, float s_lo, char* __restrict__ out) {
+    const int T = kh * kw;
+    const long per_stage = (long)NT * 64 * 64;      // one thread per (nt, lane, byte-slot b in 0..63)
+    const long total = (long)nchunks * sc * per_stage;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int b = idx & 63;
+    const int lane = (idx >> 6) & 63;
+    long rest = idx >> 12;
+    const int nt = rest % NT; rest /= NT;
+    const int st = rest % sc;
+    const int c = rest / sc;                         // channel group
+    const int r = lane & 31, hh = lane >> 5;
+    const int co = nt * 32 + r;
+    const size_t stage_b = (size_t)8 * NT * 1024;
+    char* base = out + ((size_t)c * sc + st) * stage_b;
+    auto weight = [&](int tap, int j) -> float {
+        const int chn = c * 8 + j;
+        if (tap >= T || chn >= cin || co >= cout) return 0.f;
+        float v = w[((size_t)tap * cin_total + c_off + chn) * cout + co] * wscale;
+        if (cscale != nullptr) v *= cscale[co];
+        return v;
+    };
+    if (b < 32) {
+        // fp16 part: slot b -> k-step j = b >> 3, element e = b & 7: tap = 8 st + 2 j + hh, channel e
+        const int j = b >> 3, e = b & 7;
+        const float v = weight(st * 8 + 2 * j + hh, e);
+        reinterpret_cast<_Float16*>(base)[((size_t)(j * NT + nt) * 64 + lane) * 8 + e] = (_Float16)v;
+    } else {
+        // fp8 parts: byte bb = b - 32 of the lane: tap = 8 st + 4 hh + (bb >> 3), channel bb & 7
+        const int bb = b - 32;
+        const float v = weight(st * 8 + 4 * hh + (bb >> 3), bb & 7);
+        const float lo = v - (float)(_Float16)v;
+        const float lim = 448.f;
+        const int phi = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v * s_hi, -lim), lim), 0.f, 0, false) & 0xff;
+        const int plo = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(lo * s_lo, -lim), lim), 0.f, 0, false) & 0xff;
+        char* f8 = base + 4 * NT * 1024;
+        f8[((size_t)nt * 64 + lane) * 32 + bb] = (char)phi;
+        f8[(size_t)NT * 2048 + ((size_t)nt * 64 + lane) * 32 + bb] = (char)plo;
     }
 }
 
@@ -370,7 +648,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int kh, int kw,
 
 // fp32 NHWC -> G8
 __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off, int cin,
-                                 _Float16* __restrict__ out) {
+                                 int f8c, _Float16* __restrict__ out) {
     const int cg_n = (cin + 7) >> 3;
     const size_t plane_px = (size_t)h * w;
     const size_t total = (size_t)n * cg_n * plane_px;
@@ -382,15 +660,20 @@ __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int 
     const int b = t / cg_n;
     const float* src = x + ((size_t)b * plane_px + px) * c + c_off + cg * 8;
     half8 hi, lo;
+    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float v = (cg * 8 + j < cin) ? src[j] : 0.f;
+        vv[j] = v;
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
     }
     _Float16* dst = out + ((((size_t)b * cg_n + cg) * 2) * plane_px + px) * 8;
     *reinterpret_cast<half8*>(dst) = hi;
-    *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
+    if (f8c)
+        *reinterpret_cast<int4*>(dst + plane_px * 8) = g8c_plane1(vv);
+    else
+        *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
 }
 
 // G8 -> fp32 NHWC
@@ -454,6 +737,32 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
     return s;
 }
 
+// ---- MPG_PREC_F16F8 shapes (host mirror of Pipe8<NT>) ----
+bool f8_supported(int nt) { return nt == 1 || nt == 4; }
+int f8_waves(int nt) { return nt == 4 ? 8 : 4; }
+
+SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
+    SegShape s;
+    const int waves = f8_waves(nt);
+    const int px = (16 + kh - 1) * (TW + kw - 1);
+    s.np = (px + 63) & ~63;
+    s.cgc = 1;
+    const int pieces = 2 * (s.np / 64);
+    s.ni_img = (pieces + waves - 1) / waves;
+    s.img_bytes = s.ni_img * waves * 1024;
+    s.nchunks = (cin + 7) / 8;
+    s.sc = (kh * kw + 7) / 8;
+    return s;
+}
+
+template <int NT>
+void launch_f8(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f8_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv_mfma_f8_kernel<NT>), grid, dim3(Pipe8<NT>::WAVES * 64), lds, st, a);
+}
+
 template <int NT, int PREC>
 void launch_one(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
     if (lds > 48 * 1024)
@@ -495,12 +804,13 @@ extern "C" size_t mpg_g8_bytes(int n, int h, int w, int c) {
 }
 
 extern "C" int mpg_f32_to_g8(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
-                             void* out) {
+                             int flavour, void* out) {
+    MPG_REQUIRE(flavour == MPG_G8_F16 || flavour == MPG_G8_F8C, "mpg_f32_to_g8: bad flavour %d", flavour);
     MPG_REQUIRE(x && out, "mpg_f32_to_g8: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && c_off >= 0 && cin >= 1 && c_off + cin <= c, "mpg_f32_to_g8: bad shape");
     const size_t total = (size_t)n * ((cin + 7) / 8) * h * w;
     hipLaunchKernelGGL(f32_to_g8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, h,
-                       w, c, c_off, cin, (_Float16*)out);
+                       w, c, c_off, cin, flavour == MPG_G8_F8C ? 1 : 0, (_Float16*)out);
     MPG_LAUNCH_CHECK("f32_to_g8_kernel");
 }
 
@@ -515,8 +825,13 @@ extern "C" int mpg_g8_to_f32(mpg_stream_t stream, const void* g8, int n, int h, 
 
 extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec) {
     if (kh < 1 || kw < 1 || kh > 7 || kw > 7 || cin < 1 || cout < 1 || cout > 128) return 0;
-    if (prec != MPG_PREC_F16X1 && prec != MPG_PREC_F16X3) return 0;
     const int nt = (cout + 31) / 32;
+    if (prec == MPG_PREC_F16F8) {
+        if (!f8_supported(nt)) return 0;
+        const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
+        return (size_t)ss.nchunks * ss.sc * 8 * nt * 1024;
+    }
+    if (prec != MPG_PREC_F16X1 && prec != MPG_PREC_F16X3) return 0;
     const Shape ps = pipe_shape(nt, prec);
     const SegShape ss = seg_shape(kh, kw, cin, nt, prec);
     const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
@@ -525,15 +840,26 @@ extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec
 
 extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw, int w_cin_total,
                                      int w_c_off, int cin, int cout, float wscale, const float* cout_scale, int prec,
-                                     void* out, size_t out_bytes) {
+                                     int w_exp, void* out, size_t out_bytes) {
     MPG_REQUIRE(w_hwio && out, "mpg_conv_pack_weights: null pointer");
-    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3, "mpg_conv_pack_weights: bad prec %d", prec);
+    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3 || prec == MPG_PREC_F16F8,
+                "mpg_conv_pack_weights: bad prec %d", prec);
     MPG_REQUIRE(kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7, "mpg_conv_pack_weights: kernel %dx%d unsupported", kh, kw);
     MPG_REQUIRE(cin >= 1 && w_c_off >= 0 && w_c_off + cin <= w_cin_total, "mpg_conv_pack_weights: channel range");
     MPG_REQUIRE(cout >= 1 && cout <= 128, "mpg_conv_pack_weights: cout %d not in 1..128", cout);
     const size_t need = mpg_conv_pack_size(kh, kw, cin, cout, prec);
+    MPG_REQUIRE(need > 0, "mpg_conv_pack_weights: %dx%d %d->%d not available at prec %d", kh, kw, cin, cout, prec);
     MPG_REQUIRE(out_bytes >= need, "mpg_conv_pack_weights: out buffer %zu < %zu", out_bytes, need);
     const int nt = (cout + 31) / 32;
+    if (prec == MPG_PREC_F16F8) {
+        MPG_REQUIRE(w_exp >= -100 && w_exp <= 100, "mpg_conv_pack_weights: w_exp %d out of range", w_exp);
+        const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
+        const long total = (long)ss.nchunks * ss.sc * nt * 64 * 64;
+        hipLaunchKernelGGL(pack_weights_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ss.nchunks, ss.sc,
+                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), (char*)out);
+        MPG_LAUNCH_CHECK("pack_weights_f8_kernel");
+    }
     const Shape ps = pipe_shape(nt, prec);
     const SegShape ss = seg_shape(kh, kw, cin, nt, prec);
     const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
@@ -550,11 +876,18 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(d->n >= 1 && d->h >= 1 && d->w >= 1, "mpg_conv2d_fused: bad shape %d x %d x %d", d->n, d->h, d->w);
     MPG_REQUIRE(d->cout >= 1 && d->cout <= 128, "mpg_conv2d_fused: cout %d not in 1..128", d->cout);
     MPG_REQUIRE(d->nseg >= 1 && d->nseg <= MPG_MAX_SEG, "mpg_conv2d_fused: nseg %d", d->nseg);
-    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr, "mpg_conv2d_fused: no output requested");
-    MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3, "mpg_conv2d_fused: bad prec %d", d->prec);
+    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr || d->y_g8c != nullptr, "mpg_conv2d_fused: no output requested");
+    MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3 || d->prec == MPG_PREC_F16F8,
+                "mpg_conv2d_fused: bad prec %d", d->prec);
     MPG_REQUIRE(d->act >= MPG_ACT_NONE && d->act <= MPG_ACT_TANH, "mpg_conv2d_fused: bad act %d", d->act);
     const int nt = (d->cout + 31) / 32;
-    const Shape ps = pipe_shape(nt, d->prec);
+    const bool f8 = d->prec == MPG_PREC_F16F8;
+    if (f8 && !f8_supported(nt)) {
+        mpg::set_error("mpg_conv2d_fused: MPG_PREC_F16F8 is built for cout <= 32 and 97..128 only (cout %d)", d->cout);
+        return MPG_ERR_UNSUPPORTED;
+    }
+    Shape ps = pipe_shape(nt, f8 ? MPG_PREC_F16X3 : d->prec);
+    if (f8) { ps.th = 16; ps.pt = 16 / f8_waves(nt); }
     const int npl = d->prec == MPG_PREC_F16X3 ? 2 : 1;
 
     ConvArgs a;
@@ -570,8 +903,8 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         MPG_REQUIRE((d->h % (1 << g.up_log2)) == 0 && (d->w % (1 << g.up_log2)) == 0,
                     "mpg_conv2d_fused: segment %d: %dx%d not divisible by upsample %d", s, d->h, d->w, 1 << g.up_log2);
         MPG_REQUIRE((((uintptr_t)g.x) & 15) == 0 && (((uintptr_t)g.wpack) & 15) == 0, "mpg_conv2d_fused: segment %d misaligned", s);
-        const SegShape ss = seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
-        MPG_REQUIRE(ss.sc * ps.ks * 2 <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
+        const SegShape ss = f8 ? seg_shape_f8(g.kh, g.kw, g.cin, nt) : seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
+        MPG_REQUIRE((f8 ? ss.sc * 8 : ss.sc * ps.ks * 2) <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
         SegArgs& o = a.seg[s];
         o.x = (const char*)g.x; o.w = (const char*)g.wpack;
         o.cg_seg = (g.cin + 7) / 8; o.cg_total = g.cgroups; o.g_off = g.g_off;
@@ -581,6 +914,12 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         o.pt = (g.kh - 1) / 2; o.pl = (g.kw - 1) / 2;
         o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2;
         o.np = ss.np; o.ni_img = ss.ni_img;
+        o.sw_hi = o.sw_lo = 0;
+        if (f8) {
+            MPG_REQUIRE(g.w_exp >= -100 && g.w_exp <= 100, "mpg_conv2d_fused: segment %d w_exp %d", s, g.w_exp);
+            o.sw_hi = (127 - g.w_exp) * 0x01010101;
+            o.sw_lo = (127 - g.w_exp - 11) * 0x01010101;
+        }
         max_img = ss.img_bytes > max_img ? ss.img_bytes : max_img;
     }
     for (int s = d->nseg; s < MPG_MAX_SEG; ++s) a.seg[s] = a.seg[0];
@@ -589,7 +928,9 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(!d->post_add || d->post_add_coff + d->cout <= d->post_add_stride, "mpg_conv2d_fused: post_add channel range");
     a.y = d->y;
     a.y_g8 = (char*)d->y_g8;
-    MPG_REQUIRE((((uintptr_t)d->y) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0, "mpg_conv2d_fused: misaligned output");
+    a.y_g8c = (char*)d->y_g8c;
+    MPG_REQUIRE((((uintptr_t)d->y) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0,
+                "mpg_conv2d_fused: misaligned output");
     a.zeros = zero_buffer();
     MPG_REQUIRE(a.zeros != nullptr, "mpg_conv2d_fused: could not allocate the zero page");
     a.img_bytes = max_img;
@@ -598,12 +939,17 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     a.dbg = d->reserved;
     const long nblk = (long)d->n * a.tiles_x * a.tiles_y;
     MPG_REQUIRE(nblk < (1L << 31), "mpg_conv2d_fused: grid too large");
-    const size_t lds_loop = TAPOFF_BYTES + 2 * (size_t)max_img + (size_t)ps.r * ps.ks * nt * 1024 * npl;
-    const size_t lds_epi = TAPOFF_BYTES + (size_t)4 * 32 * (nt * 32 + 4) * sizeof(float);
+    const int waves = f8 ? f8_waves(nt) : 4;
+    const size_t ring = f8 ? (size_t)3 * 8 * nt * 1024 : (size_t)ps.r * ps.ks * nt * 1024 * npl;
+    const size_t lds_loop = TAPOFF_BYTES + 2 * (size_t)max_img + ring;
+    const size_t lds_epi = TAPOFF_BYTES + (size_t)waves * 32 * (nt * 32 + 4) * sizeof(float);
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_fused: LDS budget %zu exceeds 160 KiB", lds);
     const dim3 grid((unsigned)nblk);
-    if (d->prec == MPG_PREC_F16X3)
+    if (f8) {
+        if (nt == 4) launch_f8<4>(grid, lds, (hipStream_t)stream, a);
+        else launch_f8<1>(grid, lds, (hipStream_t)stream, a);
+    } else if (d->prec == MPG_PREC_F16X3)
         launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);
     else
         launch_nt<1>(nt, grid, lds, (hipStream_t)stream, a);

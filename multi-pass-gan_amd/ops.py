@@ -5,11 +5,12 @@ enqueues hand-written HIP kernels from libmpgan_hip.so on torch's current
 stream.  Tensors are NHWC float32 on the GPU.
 """
 import ctypes
+import math
 
 import torch
 
 from . import _lib
-from ._lib import PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
+from ._lib import G8_F16, G8_F8C, PREC_F16F8, PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
 
 DEFAULT_PREC = PREC_F16X3
 
@@ -35,22 +36,32 @@ def _ptr(t):
 class G8(object):
     """A "G8" activation tensor (include/mpgan.h): [N][ceil(C/8)][2 planes hi, lo][H][W][8 x fp16]."""
 
-    __slots__ = ("buf", "n", "h", "w", "c")
+    __slots__ = ("buf", "n", "h", "w", "c", "flavour")
 
-    def __init__(self, buf, n, h, w, c):
-        self.buf, self.n, self.h, self.w, self.c = buf, n, h, w, c
+    def __init__(self, buf, n, h, w, c, flavour=G8_F16):
+        self.buf, self.n, self.h, self.w, self.c, self.flavour = buf, n, h, w, c, flavour
 
     @property
     def groups(self):
         return (self.c + 7) // 8
 
     @staticmethod
-    def empty(n, h, w, c, device):
+    def empty(n, h, w, c, device, flavour=G8_F16):
         buf = torch.empty((n, (c + 7) // 8, 2, h, w, 8), dtype=torch.float16, device=device)
-        return G8(buf, n, h, w, c)
+        return G8(buf, n, h, w, c, flavour)
 
 
-def to_g8(x, c_off=0, cin=None):
+def flavour_for(prec):
+    """the G8 flavour a launch of precision `prec` reads"""
+    return G8_F8C if prec == PREC_F16F8 else G8_F16
+
+
+def f8_available(cout):
+    """MPG_PREC_F16F8 is built for 1 and 4 output-channel tiles of 32"""
+    return (cout + 31) // 32 in (1, 4)
+
+
+def to_g8(x, c_off=0, cin=None, flavour=G8_F16):
     """fp32 NHWC x[..., c_off:c_off+cin] -> G8 (mpg_f32_to_g8)"""
     lib = _lib.load()
     x = _dev(x, "x")
@@ -58,15 +69,17 @@ def to_g8(x, c_off=0, cin=None):
         raise _lib.MpgError("to_g8: expected NHWC, got %s" % (tuple(x.shape),))
     n, h, w, c = x.shape
     cin = c - c_off if cin is None else cin
-    g = G8.empty(n, h, w, cin, x.device)
+    g = G8.empty(n, h, w, cin, x.device, flavour)
     if x.numel():
-        _lib.check(lib.mpg_f32_to_g8(_stream(), _ptr(x), n, h, w, c, c_off, cin, _ptr(g.buf)), "mpg_f32_to_g8")
+        _lib.check(lib.mpg_f32_to_g8(_stream(), _ptr(x), n, h, w, c, c_off, cin, flavour, _ptr(g.buf)), "mpg_f32_to_g8")
     return g
 
 
 def from_g8(g):
     """G8 -> fp32 NHWC (mpg_g8_to_f32)"""
     lib = _lib.load()
+    if g.flavour != G8_F16:
+        raise _lib.MpgError("from_g8: only the fp16 hi/lo flavour converts back to fp32")
     y = torch.empty((g.n, g.h, g.w, g.c), dtype=torch.float32, device=g.buf.device)
     _lib.check(lib.mpg_g8_to_f32(_stream(), _ptr(g.buf), g.n, g.h, g.w, g.c, _ptr(y)), "mpg_g8_to_f32")
     return y
@@ -75,10 +88,10 @@ def from_g8(g):
 class PackedWeights(object):
     """Weights of one conv segment in MFMA fragment order (mpg_conv_pack_weights)."""
 
-    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec")
+    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec", "w_exp")
 
-    def __init__(self, buf, kh, kw, cin, cout, prec):
-        self.buf, self.kh, self.kw, self.cin, self.cout, self.prec = buf, kh, kw, cin, cout, prec
+    def __init__(self, buf, kh, kw, cin, cout, prec, w_exp=0):
+        self.buf, self.kh, self.kw, self.cin, self.cout, self.prec, self.w_exp = buf, kh, kw, cin, cout, prec, w_exp
 
 
 def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, prec=DEFAULT_PREC):
@@ -94,10 +107,18 @@ def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, pr
         raise _lib.MpgError("mpg_conv_pack_size: unsupported conv %dx%d %d->%d" % (kh, kw, cin, cout))
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     cs = _dev(cout_scale, "cout_scale") if cout_scale is not None else None
+    w_exp = 0
+    if prec == PREC_F16F8:
+        # exponent of the fp8 weight planes: max |w_eff| * 2^w_exp <= 224 (half the e4m3 range)
+        wm = w[:, :, c_off:c_off + cin, :].abs().amax(dim=(0, 1, 2))
+        if cs is not None:
+            wm = wm * cs.abs()
+        top = float(wm.max().item()) * abs(float(wscale))
+        w_exp = 0 if top <= 0 else max(-60, min(60, int(math.floor(math.log2(224.0 / top)))))
     rc = lib.mpg_conv_pack_weights(_stream(), _ptr(w), kh, kw, cin_total, c_off, cin, cout, float(wscale), _ptr(cs),
-                                   prec, _ptr(buf), nbytes)
+                                   prec, w_exp, _ptr(buf), nbytes)
     _lib.check(rc, "mpg_conv_pack_weights")
-    return PackedWeights(buf, kh, kw, cin, cout, prec)
+    return PackedWeights(buf, kh, kw, cin, cout, prec, w_exp)
 
 
 class Segment(object):
@@ -108,7 +129,7 @@ class Segment(object):
 
     def __init__(self, x, packed, c_off=0, up_log2=0):
         if isinstance(x, torch.Tensor):
-            x = to_g8(x, c_off, packed.cin)
+            x = to_g8(x, c_off, packed.cin, flavour_for(packed.prec))
             c_off = 0
         if c_off % 8:
             raise _lib.MpgError("Segment: channel offset %d of a G8 source is not a multiple of 8" % c_off)
@@ -116,9 +137,10 @@ class Segment(object):
 
 
 def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=False, pn_eps=1e-8,
-                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, reserved=0):
+                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, want_g8c=False, reserved=0):
     """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h.
-    Returns the fp32 NHWC tensor, the G8 tensor, or (fp32, G8) when both are requested."""
+    Returns the requested outputs in the order (fp32 NHWC, G8, G8 in the F16F8 flavour): a single
+    object when one is requested, else a tuple."""
     lib = _lib.load()
     if not 1 <= len(segments) <= _lib.MAX_SEG:
         raise _lib.MpgError("conv2d_fused: %d segments (1..%d supported)" % (len(segments), _lib.MAX_SEG))
@@ -132,6 +154,9 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         g8, pk = s.x, s.packed
         if (pk.cout, pk.prec) != (p0.cout, p0.prec):
             raise _lib.MpgError("conv2d_fused: segments packed with different cout/prec")
+        if g8.flavour != flavour_for(pk.prec):
+            raise _lib.MpgError("conv2d_fused: segment %d input has G8 flavour %d, precision %d reads flavour %d"
+                                % (i, g8.flavour, pk.prec, flavour_for(pk.prec)))
         if g8.n != n or g8.h << s.up_log2 != h or g8.w << s.up_log2 != w:
             raise _lib.MpgError("conv2d_fused: segment %d input %dx%dx%d does not match output %dx%dx%d (up 2^%d)"
                                 % (i, g8.n, g8.h, g8.w, n, h, w, s.up_log2))
@@ -141,7 +166,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         g = d.seg[i]
         g.x, g.wpack = g8.buf.data_ptr(), pk.buf.data_ptr()
         g.cin, g.cgroups, g.g_off = pk.cin, g8.groups, s.g_off
-        g.kh, g.kw, g.up_log2 = pk.kh, pk.kw, s.up_log2
+        g.kh, g.kw, g.up_log2, g.w_exp = pk.kh, pk.kw, s.up_log2, pk.w_exp
     if bias is not None:
         b = _dev(bias, "bias")
         if b.numel() != p0.cout:
@@ -154,7 +179,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         if pa.dim() != 4 or tuple(pa.shape[:3]) != (n, h, w) or post_add_coff + p0.cout > pa.shape[3]:
             raise _lib.MpgError("conv2d_fused: post_add %s does not match output" % (tuple(pa.shape),))
         d.post_add, d.post_add_stride, d.post_add_coff = pa.data_ptr(), pa.shape[3], post_add_coff
-    y = y8 = None
+    y = y8 = y8c = None
     if out is not None:
         want_f32 = True
     if want_f32:
@@ -166,15 +191,17 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
                 raise _lib.MpgError("conv2d_fused: out has shape %s" % (tuple(y.shape),))
         d.y = y.data_ptr()
     if want_g8:
-        y8 = G8.empty(n, h, w, p0.cout, dev)
+        y8 = G8.empty(n, h, w, p0.cout, dev, G8_F16)
         d.y_g8 = y8.buf.data_ptr()
-    if y is None and y8 is None:
+    if want_g8c:
+        y8c = G8.empty(n, h, w, p0.cout, dev, G8_F8C)
+        d.y_g8c = y8c.buf.data_ptr()
+    outs = [o for o in (y, y8, y8c) if o is not None]
+    if not outs:
         raise _lib.MpgError("conv2d_fused: no output requested")
     d.prec, d.reserved = p0.prec, reserved
     _lib.check(lib.mpg_conv2d_fused(_stream(), ctypes.byref(d)), "mpg_conv2d_fused")
-    if y is not None and y8 is not None:
-        return y, y8
-    return y if y is not None else y8
+    return outs[0] if len(outs) == 1 else tuple(outs)
 
 
 def conv2d_direct(x, w_hwio, stride=(1, 1), wscale=1.0, cout_scale=None, bias=None, act=None, leak=0.2):

@@ -148,27 +148,28 @@ class Session(object):
         return self._f32(env, fetch)
 
     # ------------------------------------------------------------------ tensor formats
-    # A fused convolution can emit fp32 NHWC, the G8 layout its consumers DMA from, or both; its env
-    # entry is a dict {"f32": tensor | None, "g8": G8 | None}.  Every other node holds an fp32 tensor.
+    # A fused convolution can emit fp32 NHWC and / or the G8 layout (in either flavour) its consumers
+    # DMA from; its env entry is a dict {"f32": tensor | None, "g8": {flavour: G8}}.  Every other
+    # node holds an fp32 tensor.
     @staticmethod
     def _f32(env, node):
         v = env[node.id]
         if isinstance(v, dict):
             if v["f32"] is None:
-                v["f32"] = ops.from_g8(v["g8"])
+                v["f32"] = ops.from_g8(v["g8"][ops.G8_F16])
             return v["f32"]
         return v
 
     @staticmethod
-    def _g8(env, node, c_off, cin):
+    def _g8(env, node, c_off, cin, flavour):
         """(G8 tensor, channel offset inside it) holding channels [c_off, c_off+cin) of `node`"""
         v = env[node.id]
-        if isinstance(v, dict) and v["g8"] is not None and c_off % 8 == 0:
-            return v["g8"], c_off
-        key = ("g8", node.id, c_off, cin)
+        if isinstance(v, dict) and flavour in v["g8"] and c_off % 8 == 0:
+            return v["g8"][flavour], c_off
+        key = ("g8", node.id, c_off, cin, flavour)
         g = env.get(key)
         if g is None:
-            g = ops.to_g8(Session._f32(env, node), c_off, cin)
+            g = ops.to_g8(Session._f32(env, node), c_off, cin, flavour)
             env[key] = g
         return g, 0
 
@@ -194,7 +195,7 @@ class Session(object):
         done = set()
         fused_steps = []       # (node, run) of every fused convolution
         need_f32 = {fetch.id}  # nodes somebody reads as fp32 NHWC
-        need_g8 = set()        # fused outputs read by another fused convolution (aligned window)
+        need_g8 = set()        # (node id, flavour) of fused outputs read by another fused convolution
 
         def single_use(n):
             return len(consumers.get(n.id, [])) == 1 and n is not fetch
@@ -231,16 +232,18 @@ class Session(object):
         emit(fetch)
         fused_ids = set(n.id for n, _ in fused_steps)
         for n, fn in fused_steps:
+            fl = ops.flavour_for(fn.info["prec"])
             for seg in fn.info["segments"]:
                 if seg["src_id"] in fused_ids and seg["c_off"] % 8 == 0:
-                    need_g8.add(seg["src_id"])
+                    need_g8.add((seg["src_id"], fl))
                 else:
                     need_f32.add(seg["src_id"])
             if fn.info["post_add_id"] is not None:
                 need_f32.add(fn.info["post_add_id"])
         for n, fn in fused_steps:
-            fn.emit["g8"] = n.id in need_g8
-            fn.emit["f32"] = n.id in need_f32 or n.id not in need_g8
+            fn.emit["g8"] = (n.id, ops.G8_F16) in need_g8
+            fn.emit["g8c"] = (n.id, ops.G8_F8C) in need_g8
+            fn.emit["f32"] = n.id in need_f32 or not (fn.emit["g8"] or fn.emit["g8c"])
         # variables, placeholders and the fetch stay alive; everything else dies after its last reader
         plan.free_after = [[] for _ in plan.steps]
         keep = set(n.id for n, _ in plan.steps if n.op in ("variable", "placeholder"))
@@ -323,22 +326,30 @@ class Session(object):
         for pat, pr in self.prec_map:
             if pat in lead:
                 prec = pr
+        if prec == ops.PREC_F16F8 and not ops.f8_available(cout):
+            prec = ops.PREC_F16X3      # F16F8 is built for 1 and 4 cout tiles; other widths keep the fp16 split
 
-        emit = {"f32": True, "g8": False}
+        emit = {"f32": True, "g8": False, "g8c": False}
 
         def run(env, segs=segs, terms=terms, prec=prec):
             seg_objs = []
             for (src, c_off_src, up, term, w_off, cin) in segs:
                 pk = self._packed_for(term, w_off, cin, prec)
-                g8, off = self._g8(env, src, c_off_src, cin)
+                g8, off = self._g8(env, src, c_off_src, cin, ops.flavour_for(prec))
                 seg_objs.append(ops.Segment(g8, pk, off, up))
             bias = self._bias_for(terms)
             pa = self._f32(env, post_add) if post_add is not None else None
             res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
-                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"])
-            if emit["f32"] and emit["g8"]:
-                return {"f32": res[0], "g8": res[1]}
-            return {"f32": res, "g8": None} if emit["f32"] else {"f32": None, "g8": res}
+                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"], want_g8c=emit["g8c"])
+            res = list(res) if isinstance(res, tuple) else [res]
+            out = {"f32": None, "g8": {}}
+            if emit["f32"]:
+                out["f32"] = res.pop(0)
+            if emit["g8"]:
+                out["g8"][ops.G8_F16] = res.pop(0)
+            if emit["g8c"]:
+                out["g8"][ops.G8_F8C] = res.pop(0)
+            return out
 
         run.emit = emit
         run.info = {

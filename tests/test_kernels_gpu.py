@@ -95,6 +95,63 @@ def test_g8_roundtrip_and_chained_convs(gpu_ops):
         assert rel_l2(y3.cpu().numpy(), O.conv2d_same(ref1[..., 8:40], w3)) < tol
 
 
+F8_CASES = [
+    # n, h, w, cin, cout, k, act, pixel_norm  (cout <= 32 or 97..128: the widths F16F8 is built for)
+    (1, 16, 32, 128, 128, 5, "relu", False),
+    (2, 16, 64, 8, 128, 5, "relu", False),
+    (1, 19, 40, 128, 32, 5, None, False),      # ragged tile edges
+    (1, 16, 32, 32, 8, 5, "relu", False),
+    (1, 32, 32, 6, 128, 3, "relu", True),
+    (2, 16, 32, 1, 2, 5, "relu", False),
+    (1, 16, 32, 12, 1, 1, None, False),
+    (1, 16, 32, 24, 100, 4, "lrelu", False),
+]
+
+
+@pytest.mark.parametrize("case", F8_CASES)
+def test_conv2d_fused_f16f8(gpu_ops, case):
+    """MPG_PREC_F16F8: fp16 main product + two fp8 (MX e4m3) correction products; ~2^-15 per operand,
+    held to 1.5e-4 relative L2 per layer (F16X1 gives ~3e-4..2e-3, F16X3 ~1e-6)."""
+    n, h, w, cin, cout, k, act, pn = case
+    rng = _rng(2000 + F8_CASES.index(case))
+    x = np.abs(rng.standard_normal((n, h, w, cin))).astype(np.float32) if cin > 8 else rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = float(O.wscale(wt.shape))
+    ref = O.activation(O.bias_add(O.conv2d_same(x, (wt.astype(np.float64) * ws).astype(np.float32)), b), act)
+    if pn:
+        ref = O.pixel_norm(ref)
+    pk = gpu_ops.pack_conv_weights(_t(wt), wscale=ws, prec=2)
+    y, g = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (h, w), bias=_t(b), act=act, pixel_norm=pn,
+                                want_f32=True, want_g8c=True)
+    err = rel_l2(y.cpu().numpy(), ref)
+    assert err < 1.5e-4, err
+    assert g.flavour == gpu_ops.G8_F8C and g.c == cout
+    # F16X1 on the same data is clearly worse: the corrections do their job
+    y1 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), gpu_ops.pack_conv_weights(_t(wt), wscale=ws, prec=1))], (h, w),
+                              bias=_t(b), act=act, pixel_norm=pn)
+    assert err < 0.5 * rel_l2(y1.cpu().numpy(), ref)
+
+
+def test_f16f8_chain_and_unavailable_width(gpu_ops, mpg):
+    """two F16F8 launches chained through the F8C flavour; widths of 2 or 3 cout tiles are refused"""
+    from mpgan_amd._lib import MpgError
+    rng = _rng(77)
+    x = rng.standard_normal((1, 16, 32, 8)).astype(np.float32)
+    w1 = rng.standard_normal((5, 5, 8, 128)).astype(np.float32) * 0.07
+    w2 = rng.standard_normal((5, 5, 128, 32)).astype(np.float32) * 0.02
+    ref = O.conv2d_same(O.relu(O.conv2d_same(x, w1)), w2)
+    p1 = gpu_ops.pack_conv_weights(_t(w1), prec=2)
+    p2 = gpu_ops.pack_conv_weights(_t(w2), prec=2)
+    g1 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), p1)], (16, 32), act="relu", want_f32=False, want_g8c=True)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(g1, p2)], (16, 32))
+    assert rel_l2(y.cpu().numpy(), ref) < 2.5e-4
+    with pytest.raises(MpgError):
+        gpu_ops.pack_conv_weights(_t(np.zeros((3, 3, 8, 64), np.float32)), prec=2)
+    with pytest.raises(MpgError):   # wrong flavour for the launch precision
+        gpu_ops.conv2d_fused([gpu_ops.Segment(gpu_ops.to_g8(_t(x)), p1)], (16, 32))
+
+
 def test_conv2d_fused_exact_integers(gpu_ops):
     """Small-integer data is exact in fp16: the MFMA path must be bit-exact, which pins
     the fragment layouts (asymmetric weights catch a transposed operand map)."""
@@ -102,7 +159,13 @@ def test_conv2d_fused_exact_integers(gpu_ops):
     x = rng.integers(-3, 4, size=(1, 16, 64, 16)).astype(np.float32)
     wt = rng.integers(-2, 3, size=(5, 5, 16, 40)).astype(np.float32)
     ref = O.conv2d_same(x, wt)
-    for prec in (1, 3):
+    for prec in (1, 2, 3):      # prec 2 (F16F8): cout 40 has 2 tiles -> use the 128-wide variant below
+        if prec == 2:
+            wt2 = rng.integers(-2, 3, size=(5, 5, 16, 128)).astype(np.float32)
+            pk = gpu_ops.pack_conv_weights(_t(wt2), prec=2)
+            y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (16, 64))
+            assert np.array_equal(y.cpu().numpy(), O.conv2d_same(x, wt2))
+            continue
         pk = gpu_ops.pack_conv_weights(_t(wt), prec=prec)
         y = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), pk)], (16, 64))
         assert np.array_equal(y.cpu().numpy(), ref)

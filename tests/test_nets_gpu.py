@@ -17,7 +17,8 @@ DEV = "cuda:0"
 
 # F16X1 is the opt-in fast mode: measured 1.6e-3..3.2e-3 end to end, i.e. OUTSIDE the 1e-3 target;
 # it is bounded here at 5e-3 so the mode stays covered.  The default (and bench) mode is F16X3.
-TOL = {3: 1e-4, 1: 5e-3}
+# F16F8 (fp16 product + fp8 correction products) is held to 5e-4, half the north_star tolerance.
+TOL = {3: 1e-4, 2: 5e-4, 1: 5e-3}
 
 
 def _t(a):
@@ -30,7 +31,7 @@ def MP(mpg):
     return multipass
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", [3, 2, 1])
 @pytest.mark.parametrize("nch,mode", [(1, 2), (4, 2), (1, 1), (4, 1)])
 def test_gen_resnet(MP, prec, nch, mode):
     low, up = 8, 4
@@ -55,7 +56,7 @@ NET_CFGS = {
 }
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", [3, 2, 1])
 @pytest.mark.parametrize("name", ["net1", "net2", "net3"])
 def test_growing_gen(MP, prec, name):
     cfg = NET_CFGS[name]
@@ -78,7 +79,7 @@ def test_growing_gen(MP, prec, name):
     assert rel_l2(y, ref) < TOL[prec], rel_l2(y, ref)
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", [3, 2, 1])
 @pytest.mark.parametrize("nch", [1, 4])
 def test_two_pass_4x_small(MP, mpg, prec, nch):
     from mpgan_amd.synthetic import synthetic_volume
@@ -97,7 +98,7 @@ def test_two_pass_4x_small(MP, mpg, prec, nch):
     assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy())
 
 
-@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("prec", [3, 2, 1])
 def test_two_pass_4x_c1_reduced(MP, mpg, prec):
     """BASELINE config C1 (4x two-pass, density only) at 16^3 -> 64^3, checked against the
     PyTorch-CPU twin of the oracle (itself checked against the numpy oracle in test_oracle.py)."""
@@ -119,7 +120,7 @@ def test_two_pass_4x_c1_reduced(MP, mpg, prec):
     assert rel_l2(out.cpu().numpy(), ref) < TOL[prec], rel_l2(out.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("prec", [3])
+@pytest.mark.parametrize("prec", [3, 2])
 @pytest.mark.parametrize("nets", [1, 2, 3])
 def test_multipass_8x_small(MP, mpg, prec, nets):
     from mpgan_amd.synthetic import synthetic_volume
