@@ -72,6 +72,13 @@ def dominant_kernel_roofline(mpg, device, prec, iters=20):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * (25 * 128 + 8) * 128 * h * w * n
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch of this very launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
+    # per MI355X_MICROARCH.md + WRITE_SIZE; profiles/r01/roofline_pmc_b1convB.json); null for other modes
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "roofline_pmc_b1convB.json")
+    if prec == 2 and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
     return {
         "bound": "mfma",
         "kernel": "conv_mfma%s_kernel<NT=4> prec %d (resBlock1 convB 5x5 128->128 + 1x1 8->128 shortcut, 8 slices of 256^2)" % ("_f8" if prec == 2 else "", prec),
@@ -79,7 +86,8 @@ def dominant_kernel_roofline(mpg, device, prec, iters=20):
         "peak": DENSE_F16_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(achieved / DENSE_F16_MFMA_PEAK_TFLOPS, 4),
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_source": "profiles/r01/roofline_pmc_b1convB.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" if traffic else None,
         "launch_ms": round(ms, 4),
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 fp8 (MX, K=64)", 1: "1 fp16"}[prec],
