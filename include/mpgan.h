@@ -40,7 +40,7 @@ enum { MPG_ACT_NONE = 0, MPG_ACT_RELU = 1, MPG_ACT_LRELU = 2, MPG_ACT_TANH = 3 }
 enum { MPG_PREC_F16X1 = 1, MPG_PREC_F16F8 = 2, MPG_PREC_F16X3 = 3 };
 /* F16F8: the fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and a_hi*w_lo
  *        on the block-scaled fp8 (e4m3) MFMA path at twice the fp16 rate per K: ~2^-15 per
- *        operand, 2/3 of the F16X3 matrix work.  Built for cout <= 32 and cout in 97..128. */
+ *        operand, 2/3 of the F16X3 matrix work. */
 
 /* flavours of a G8 tensor's second plane: fp16 lo (F16X3 / F16X1 launches) or the packed
  * {8 x fp8 hi | 8 x fp8 lo} bytes the F16F8 launches read */

@@ -244,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
 }
 
 template <int NT, int PREC>
-__global__ __launch_bounds__(256, (NT >= 3 ? 2 : 3)) void conv_mfma_kernel(const ConvArgs a_unused) {
+__global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const ConvArgs a_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const auto& a = *ap;
@@ -403,7 +403,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 
 template <int NT>
 struct Pipe8 {
-    static constexpr int WAVES = (NT == 4) ? 8 : 4;
+    static constexpr int WAVES = (NT == 1) ? 4 : 8;
     static constexpr int PT = 16 / WAVES;                  // tile rows per wave
     static constexpr int TH = 16;
     static constexpr int WF16 = 4 * NT * 1024;             // four fp16 k-steps
@@ -738,8 +738,8 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
 }
 
 // ---- MPG_PREC_F16F8 shapes (host mirror of Pipe8<NT>) ----
-bool f8_supported(int nt) { return nt == 1 || nt == 4; }
-int f8_waves(int nt) { return nt == 4 ? 8 : 4; }
+bool f8_supported(int nt) { return nt >= 1 && nt <= 4; }
+int f8_waves(int nt) { return nt == 1 ? 4 : 8; }
 
 SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
     SegShape s;
@@ -883,7 +883,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     const int nt = (d->cout + 31) / 32;
     const bool f8 = d->prec == MPG_PREC_F16F8;
     if (f8 && !f8_supported(nt)) {
-        mpg::set_error("mpg_conv2d_fused: MPG_PREC_F16F8 is built for cout <= 32 and 97..128 only (cout %d)", d->cout);
+        mpg::set_error("mpg_conv2d_fused: MPG_PREC_F16F8 not available for cout %d", d->cout);
         return MPG_ERR_UNSUPPORTED;
     }
     Shape ps = pipe_shape(nt, f8 ? MPG_PREC_F16X3 : d->prec);
@@ -947,8 +947,12 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_fused: LDS budget %zu exceeds 160 KiB", lds);
     const dim3 grid((unsigned)nblk);
     if (f8) {
-        if (nt == 4) launch_f8<4>(grid, lds, (hipStream_t)stream, a);
-        else launch_f8<1>(grid, lds, (hipStream_t)stream, a);
+        switch (nt) {
+            case 1: launch_f8<1>(grid, lds, (hipStream_t)stream, a); break;
+            case 2: launch_f8<2>(grid, lds, (hipStream_t)stream, a); break;
+            case 3: launch_f8<3>(grid, lds, (hipStream_t)stream, a); break;
+            default: launch_f8<4>(grid, lds, (hipStream_t)stream, a); break;
+        }
     } else if (d->prec == MPG_PREC_F16X3)
         launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);
     else

@@ -57,8 +57,8 @@ def flavour_for(prec):
 
 
 def f8_available(cout):
-    """MPG_PREC_F16F8 is built for 1 and 4 output-channel tiles of 32"""
-    return (cout + 31) // 32 in (1, 4)
+    """MPG_PREC_F16F8 is built for every output width of the fused convolution (1..128)"""
+    return 1 <= cout <= 128
 
 
 def to_g8(x, c_off=0, cin=None, flavour=G8_F16):

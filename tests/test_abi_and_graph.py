@@ -113,11 +113,13 @@ def test_fusion_plan(mpg):
     gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None, prec=2)
     lf = [e for e in gf.sess.plan_summary(gf.sampler) if e["kind"] == "conv2d_fused"]
     assert all(e["prec"] == 2 for e in lf) and all(e["emit"]["g8c"] and not e["emit"]["g8"] for e in lf[:-1])
-    # the 8x nets mix widths: 64- and 96-channel launches stay on the fp16 split, tensors feeding both get both flavours
+    # a per-launch precision map mixes modes; a tensor feeding both kinds of launch is emitted in both G8 flavours
     g8x = MP.Generator("growing_gen", dict(tile_low=8, up_res=8, channels=4, first_gen=True, filter_size=3, start_fms=256,
-                                           max_fms=256, add_adj=True, first_nn_arch=True), None, prec=2)
+                                           max_fms=256, add_adj=True, first_nn_arch=True), None, prec=2,
+                       prec_map=[("genBlock4/g_cA_second", 3)])
     l8 = [e for e in g8x.sess.plan_summary(g8x.sampler) if e["kind"] == "conv2d_fused"]
     assert set(e["prec"] for e in l8) == {2, 3}
+    assert any(e["emit"]["g8"] and e["emit"]["g8c"] for e in l8)
     assert [len(e["segments"]) for e in launches] == [1, 2, 1, 2, 1, 2, 1, 2]
     assert launches[0]["segments"][0]["up_log2"] == 2 and launches[1]["segments"][1]["up_log2"] == 2
     assert all(e["act"] == "relu" for e in launches)
