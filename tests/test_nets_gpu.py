@@ -135,3 +135,36 @@ def test_multipass_8x_small(MP, mpg, prec, nets):
     out = MP.multipass_8x(gens, _t(low), up)
     assert out.shape == (32, 32, 32)
     assert rel_l2(out.cpu().numpy(), ref) < TOL[prec], rel_l2(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("nch", [1, 4])
+def test_disc_binclass_forward(mpg, nch):
+    """4x spatial discriminator forward (multipassGAN-4x.py:572-620): strided 4x4 convs, batch norm
+    (inference), lrelu, flatten + FC, through the same builder / session as the generators."""
+    from mpgan_amd import graph as G
+    from mpgan_amd import nets
+    from mpgan_amd.session import Session, VariableStore
+    low, up = 4, 4
+    rng = np.random.default_rng(9)
+    x_low = rng.random((3, low, low, nch)).astype(np.float32)
+    y_high = rng.random((3, low * up, low * up, 1)).astype(np.float32)
+    ps = ON.ParamSource(seed=13)
+    # the reference slices the FIRST n_input/C entries of the flat generator input (4x.py:582-583)
+    flat = x_low.reshape(3, -1)
+    dens = flat[:, : low * low].reshape(3, low, low, 1)
+    ref = ON.disc_binclass(ps, dens, y_high, up, 2, True)
+    prev = G.get_default_graph()
+    g = G.reset_default_graph()
+    try:
+        xin = G.placeholder([None, low * low * nch])
+        yin = G.placeholder([None, (low * up) ** 2])
+        outs = nets.disc_binclass(xin, yin, low, up, low * low * nch, nch, 2, use_batch_norm=True)
+    finally:
+        G._default_graph[0] = prev
+    assert sorted(g.variables) == sorted(ps.params)
+    sess = Session(graph=g, variables=VariableStore(DEV))
+    sess.vars.load(ps.params)
+    got = sess.run(list(outs), {xin: flat, yin: y_high.reshape(3, -1)})
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        assert rel_l2(a, b) < 1e-5, rel_l2(a, b)
