@@ -448,7 +448,7 @@ class Session(object):
         key = ("fold", term.conv.id)
         if key in self._folded:
             return self._folded[key]
-        cout = term.conv.shape[3]
+        cout = term.conv.shape[-1]
         b = self.vars.get(term.bias.inputs[1].attrs["var"]).double() if term.bias is not None else \
             torch.zeros(cout, dtype=torch.float64, device=self.device)
         if term.bn is not None:
