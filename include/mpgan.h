@@ -187,6 +187,51 @@ int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_total, size_t h
 /* out[i] = v[i] < cutoff ? 0 : v[i]   (multipassGAN-4x.py:1156-1157) */
 int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out);
 
+/* ------------------------------------------------------------------------
+ * Training step: what tf.gradients produces for
+ * the layers of GAN.py, and the optimiser update.  fp32 NHWC device tensors;
+ * geometry is tf.nn.conv2d SAME of an [n,h,w,cin] input (GAN.py:686-691).
+ * ------------------------------------------------------------------------ */
+/* d loss / d W for W stored unscaled (GAN.py:664-668): dw[kh,kw,cin,cout] =
+ * wscale * sum_p x[p + tap] * dy[p].  dy is [n, ceil(h/sh), ceil(w/sw), cout]; dw is overwritten. */
+int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* dy,
+                     int cout, int kh, int kw, int stride_h, int stride_w, float wscale, float* dw);
+/* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
+ * convs, multipassGAN-4x.py:607-614).  Stride-1 odd filters can instead run mpg_conv2d_fused on dy
+ * with the flipped, transposed filter. */
+int mpg_conv2d_dgrad(mpg_stream_t stream, const float* dy, int n, int h, int w, int cin,
+                     const float* w_hwio, int cout, int kh, int kw, int stride_h, int stride_w,
+                     float wscale, float* dx);
+/* out[c] = sum over pixels of x[p, c]  (bias gradient, GAN.py:683) */
+int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out);
+/* tf.contrib.layers.batch_norm(is_training=True) (GAN.py:110): batch mean / biased variance over
+ * all pixels, y = act((x - mean) * rsqrt(var + eps) * gamma + beta); the moments are returned for
+ * the moving-average update done by the caller. */
+int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
+                     const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
+                     float* batch_var);
+/* gradient of the normalisation above (dy is taken before the activation) */
+int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
+                     const float* batch_mean, const float* batch_var, const float* gamma, float eps,
+                     float* dx, float* dgamma, float* dbeta);
+/* dx = dy * act'(.) written through the activation OUTPUT y (relu, lrelu GAN.py:733-737, tanh) */
+int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak, float* dx);
+/* gradient of GAN.pixel_norm (GAN.py:472-474) */
+int mpg_pixel_norm_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c, float eps,
+                       float* dx);
+/* gradient of the nearest upsample by integer factors (GAN.py:517; dy is [n,oh,ow,c]) */
+int mpg_resize_nearest_bwd(mpg_stream_t stream, const float* dy, int n, int oh, int ow, int c, float* dx,
+                           int h, int w);
+/* gradient of mpg_avg_pool2 (dx is [n,h,w,c], dy [n,h/2,w/2,c]) */
+int mpg_avg_pool2_bwd(mpg_stream_t stream, const float* dy, int n, int h, int w, int c, float* dx);
+/* lerp(x, y, t) = x + (y - x) * t with t already clipped to [0,1] (multipassGAN-8x.py:598-599); x NULL = zeros */
+int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, size_t n, float t, float* out);
+/* tf.train.AdamOptimizer update on a flat parameter buffer (multipassGAN-4x.py:880-902):
+ * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t * m / (sqrt(v) + eps), with
+ * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, size_t n,
+                  float lr_t, float beta1, float beta2, float eps);
+
 #ifdef __cplusplus
 }
 #endif

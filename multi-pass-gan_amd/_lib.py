@@ -95,6 +95,18 @@ PROTOTYPES = {
     "mpg_volume_transpose": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P]),
     "mpg_add_adjacent": (_I, [_P, _P, _I, _Z, _I, _I, _I, _P]),
     "mpg_cutoff": (_I, [_P, _P, _Z, _F, _P]),
+    # training step
+    "mpg_conv2d_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),
+    "mpg_bn_train_fwd": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P]),
+    "mpg_bn_train_bwd": (_I, [_P, _P, _P, _Z, _I, _P, _P, _P, _F, _P, _P, _P]),
+    "mpg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    "mpg_pixel_norm_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
+    "mpg_resize_nearest_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
+    "mpg_avg_pool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mpg_lerp": (_I, [_P, _P, _P, _Z, _F, _P]),
+    "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F]),
 }
 
 _lib = None

@@ -1,0 +1,476 @@
+// Backward / training companions of the convolution:
+// weight gradient (register-tiled fp32 contraction over pixels, split over the pixel range,
+// accumulated with fp32 atomics), data gradient for strided / even-sized filters, batch-norm
+// with batch statistics (forward + backward), activation / pixel-norm / resize / pool backward,
+// lerp, per-channel sums and the TF-flavoured Adam update.  All tensors fp32 NHWC on the device.
+#include "mpgan_internal.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + BLK - 1) / BLK); }
+
+struct ConvGeom {
+    int n, h, w, cin, oh, ow, cout, kh, kw, sh, sw, pt, pl;
+};
+
+// ---------------------------------------------------------------- weight gradient
+// dw[ky][kx][ci][co] += wscale * sum_p x[p shifted by (ky,kx)][ci] * dy[p][co]
+// block = one tap, a (16*MI) x (16*NI) tile of (ci, co), one slice of the pixel range.
+template <int MI, int NI>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    float* __restrict__ dw, ConvGeom g, float wscale,
+                                                    int ci_tiles, int co_tiles, size_t pix_per_split) {
+    constexpr int TM = 16 * MI, TN = 16 * NI, TK = 8;
+    __shared__ float xs[TK][TM + 4];
+    __shared__ float ds[TK][TN + 4];
+    __shared__ long long xoff[TK];
+    __shared__ long long doff[TK];
+
+    int bid = blockIdx.x;
+    const int co_t = bid % co_tiles; bid /= co_tiles;
+    const int ci_t = bid % ci_tiles; bid /= ci_tiles;
+    const int tap = bid;
+    const int ky = tap / g.kw, kx = tap % g.kw;
+    const int ci0 = ci_t * TM, co0 = co_t * TN;
+    const size_t P = (size_t)g.n * g.oh * g.ow;
+    const size_t p_begin = (size_t)blockIdx.y * pix_per_split;
+    const size_t p_end = min(P, p_begin + pix_per_split);
+    const int tid = threadIdx.x;
+    const int ty = tid / 16, tx = tid % 16;
+
+    float acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = 0.f;
+
+    for (size_t p0 = p_begin; p0 < p_end; p0 += TK) {
+        if (tid < TK) {
+            const size_t p = p0 + tid;
+            long long xo = -1, dofs = -1;
+            if (p < p_end) {
+                const int ox = (int)(p % g.ow);
+                const size_t r = p / g.ow;
+                const int oy = (int)(r % g.oh);
+                const int b = (int)(r / g.oh);
+                const int iy = oy * g.sh + ky - g.pt, ix = ox * g.sw + kx - g.pl;
+                dofs = (long long)p * g.cout;
+                if (iy >= 0 && iy < g.h && ix >= 0 && ix < g.w) xo = (((long long)b * g.h + iy) * g.w + ix) * g.cin;
+            }
+            xoff[tid] = xo;
+            doff[tid] = dofs;
+        }
+        __syncthreads();
+        for (int e = tid; e < TK * TM; e += BLK) {
+            const int pp = e / TM, c = e % TM;
+            const long long o = xoff[pp];
+            xs[pp][c] = (o >= 0 && ci0 + c < g.cin) ? x[o + ci0 + c] : 0.f;
+        }
+        for (int e = tid; e < TK * TN; e += BLK) {
+            const int pp = e / TN, c = e % TN;
+            const long long o = doff[pp];
+            ds[pp][c] = (o >= 0 && xoff[pp] >= 0 && co0 + c < g.cout) ? dy[o + co0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            float a[MI], bq[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = xs[k][ty * MI + i];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bq[j] = ds[k][tx * NI + j];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = fmaf(a[i], bq[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int ci = ci0 + ty * MI + i;
+        if (ci >= g.cin) continue;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int co = co0 + tx * NI + j;
+            if (co < g.cout && acc[i][j] != 0.f)
+                atomicAdd(dw + ((size_t)tap * g.cin + ci) * g.cout + co, acc[i][j] * wscale);
+        }
+    }
+}
+
+template <int MI, int NI>
+int launch_wgrad(hipStream_t s, const float* x, const float* dy, float* dw, const ConvGeom& g, float wscale) {
+    constexpr int TM = 16 * MI, TN = 16 * NI;
+    const int ci_tiles = (g.cin + TM - 1) / TM, co_tiles = (g.cout + TN - 1) / TN;
+    const size_t tiles = (size_t)g.kh * g.kw * ci_tiles * co_tiles;
+    const size_t P = (size_t)g.n * g.oh * g.ow;
+    size_t split = (2048 + tiles - 1) / tiles;
+    const size_t max_split = (P + 127) / 128;
+    if (split > max_split) split = max_split;
+    if (split < 1) split = 1;
+    if (split > 65535) split = 65535;
+    size_t pps = (P + split - 1) / split;
+    pps = (pps + 7) & ~(size_t)7;
+    split = (P + pps - 1) / pps;
+    hipLaunchKernelGGL((wgrad_kernel<MI, NI>), dim3((unsigned)tiles, (unsigned)split), dim3(BLK), 0, s, x, dy, dw, g,
+                       wscale, ci_tiles, co_tiles, pps);
+    return 0;
+}
+
+inline int micro(int c) { return c > 64 ? 8 : c > 32 ? 4 : c > 16 ? 2 : 1; }
+
+// ---------------------------------------------------------------- data gradient (any stride / filter)
+// dx[b,iy,ix,ci] = wscale * sum_{ky,kx,co} dy[b,oy,ox,co] * w[ky,kx,ci,co],  oy*sh + ky - pt == iy
+__global__ void dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, float* __restrict__ dx,
+                             ConvGeom g, float wscale) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)g.n * g.h * g.w * g.cin;
+    if (idx >= total) return;
+    const int ci = idx % g.cin;
+    size_t p = idx / g.cin;
+    const int ix = p % g.w; p /= g.w;
+    const int iy = p % g.h;
+    const int b = p / g.h;
+    float acc = 0.f;
+    for (int ky = 0; ky < g.kh; ++ky) {
+        const int ny = iy + g.pt - ky;
+        if (ny < 0 || ny % g.sh) continue;
+        const int oy = ny / g.sh;
+        if (oy >= g.oh) continue;
+        for (int kx = 0; kx < g.kw; ++kx) {
+            const int nx = ix + g.pl - kx;
+            if (nx < 0 || nx % g.sw) continue;
+            const int ox = nx / g.sw;
+            if (ox >= g.ow) continue;
+            const float* dp = dy + (((size_t)b * g.oh + oy) * g.ow + ox) * g.cout;
+            const float* wp = wt + ((size_t)(ky * g.kw + kx) * g.cin + ci) * g.cout;
+            for (int co = 0; co < g.cout; ++co) acc = fmaf(dp[co], wp[co], acc);
+        }
+    }
+    dx[idx] = acc * wscale;
+}
+
+// ---------------------------------------------------------------- per-channel sums over pixels
+// MODE 0: sum x            MODE 1: sum (x - m)^2 with m = aux0[c] * inv_n
+// MODE 2: sum a, sum a*(x - mean)*invstd  (a = dy; two outputs)
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                       size_t npix, int c, int lanes, const float* __restrict__ aux0,
+                                                       const float* __restrict__ aux1, float inv_n, float eps,
+                                                       float* __restrict__ out0, float* __restrict__ out1,
+                                                       size_t pix_per_block) {
+    __shared__ float red0[BLK];
+    __shared__ float red1[BLK];
+    const int tid = threadIdx.x;
+    const int ppi = BLK / lanes;                 // pixels per iteration
+    const int lane = tid % lanes, row = tid / lanes;
+    const int ch = blockIdx.y * lanes + lane;
+    const size_t p_begin = (size_t)blockIdx.x * pix_per_block;
+    const size_t p_end = min(npix, p_begin + pix_per_block);
+    float s0 = 0.f, s1 = 0.f;
+    if (ch < c) {
+        float m = 0.f, is = 0.f;
+        if (MODE == 1) m = aux0[ch] * inv_n;
+        if (MODE == 2) { m = aux0[ch]; is = rsqrtf(aux1[ch] + eps); }
+        for (size_t p = p_begin + row; p < p_end; p += ppi) {
+            const float v = a[p * c + ch];
+            if (MODE == 0) s0 += v;
+            if (MODE == 1) { const float d = v - m; s0 = fmaf(d, d, s0); }
+            if (MODE == 2) { s0 += v; s1 = fmaf(v, (x[p * c + ch] - m) * is, s1); }
+        }
+    }
+    red0[tid] = s0;
+    red1[tid] = s1;
+    __syncthreads();
+    if (row == 0 && ch < c) {
+        for (int r = 1; r < ppi; ++r) { s0 += red0[r * lanes + lane]; s1 += red1[r * lanes + lane]; }
+        atomicAdd(out0 + ch, s0);
+        if (MODE == 2) atomicAdd(out1 + ch, s1);
+    }
+}
+
+template <int MODE>
+void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix, int c, const float* aux0,
+                     const float* aux1, float inv_n, float eps, float* out0, float* out1) {
+    int lanes = 1;
+    while (lanes < c && lanes < BLK) lanes <<= 1;
+    const int cblocks = (c + lanes - 1) / lanes;
+    const int ppi = BLK / lanes;
+    size_t blocks = (npix + (size_t)ppi * 16 - 1) / ((size_t)ppi * 16);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    const size_t ppb = (npix + blocks - 1) / blocks;
+    blocks = (npix + ppb - 1) / ppb;
+    hipLaunchKernelGGL((chan_sum_kernel<MODE>), dim3((unsigned)blocks, cblocks), dim3(BLK), 0, s, a, x, npix, c, lanes,
+                       aux0, aux1, inv_n, eps, out0, out1, ppb);
+}
+
+__global__ void scale_vec_kernel(float* v, int c, float s) {
+    const int i = blockIdx.x * BLK + threadIdx.x;
+    if (i < c) v[i] *= s;
+}
+
+// y = act((x - mean) * rsqrt(var + eps) * gamma + beta)
+__global__ void bn_apply_kernel(const float* __restrict__ x, size_t total, int c, const float* __restrict__ mean,
+                                const float* __restrict__ var, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, int act, float leak, float* __restrict__ y) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const float v = (x[idx] - mean[ch]) * rsqrtf(var[ch] + eps) * gamma[ch] + beta[ch];
+    y[idx] = mpg::apply_act(v, act, leak);
+}
+
+// dx = gamma * invstd * (dy - dbeta/N - xhat * dgamma/N)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t total, int c,
+                                    const float* __restrict__ mean, const float* __restrict__ var,
+                                    const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float eps, float inv_n, float* __restrict__ dx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const float is = rsqrtf(var[ch] + eps);
+    const float xh = (x[idx] - mean[ch]) * is;
+    dx[idx] = gamma[ch] * is * (dy[idx] - dbeta[ch] * inv_n - xh * dgamma[ch] * inv_n);
+}
+
+// ---------------------------------------------------------------- elementwise backward
+// derivative expressed through the activation OUTPUT y (relu: y>0; lrelu: slope 1 / leak by sign of y,
+// 0.5(1+leak) at 0 as tf.abs has a zero gradient there, GAN.py:733-737; tanh: 1 - y^2)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int act,
+                               float leak, float* __restrict__ dx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    const float o = y[idx];
+    float d = 1.f;
+    if (act == MPG_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
+    else if (act == MPG_ACT_LRELU) d = o > 0.f ? 1.f : (o < 0.f ? leak : 0.5f * (1.f + leak));
+    else if (act == MPG_ACT_TANH) d = 1.f - o * o;
+    dx[idx] = dy[idx] * d;
+}
+
+// y = x * r, r = rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y))
+__global__ void pixel_norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t npix, int c,
+                                      float eps, float* __restrict__ dx) {
+    const size_t p = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (p >= npix) return;
+    const float* xp = x + p * c;
+    const float* dp = dy + p * c;
+    float ss = 0.f, dot = 0.f;
+    for (int i = 0; i < c; ++i) { ss = fmaf(xp[i], xp[i], ss); dot = fmaf(dp[i], xp[i], dot); }
+    const float r = rsqrtf(ss / c + eps);
+    const float k = dot * r * r / c;     // mean_c(dy*y) * r / x-scale
+    for (int i = 0; i < c; ++i) dx[p * c + i] = r * (dp[i] - xp[i] * k);
+}
+
+// nearest upsample by integer factors: dx[iy,ix] = sum of the fy x fx block of dy
+__global__ void resize_nearest_bwd_kernel(const float* __restrict__ dy, int n, int oh, int ow, int c,
+                                          float* __restrict__ dx, int h, int w, float scale) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ix = p % w; p /= w;
+    const int iy = p % h;
+    const int b = p / h;
+    const int fy = oh / h, fx = ow / w;
+    float s = 0.f;
+    for (int dyy = 0; dyy < fy; ++dyy)
+        for (int dxx = 0; dxx < fx; ++dxx)
+            s += dy[(((size_t)b * oh + iy * fy + dyy) * ow + ix * fx + dxx) * c + ch];
+    dx[idx] = s * scale;
+}
+
+// 2x2 average pool backward: every input pixel receives a quarter of its output pixel
+__global__ void avg_pool2_bwd_kernel(const float* __restrict__ dy, int n, int h, int w, int c,
+                                     float* __restrict__ dx) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ix = p % w; p /= w;
+    const int iy = p % h;
+    const int b = p / h;
+    const int oh = h / 2, ow = w / 2;
+    const int oy = iy / 2, ox = ix / 2;
+    dx[idx] = (oy < oh && ox < ow) ? 0.25f * dy[(((size_t)b * oh + oy) * ow + ox) * c + ch] : 0.f;
+}
+
+// out = x + (y - x) * t   (x may be null: zeros)
+__global__ void lerp_kernel(const float* __restrict__ x, const float* __restrict__ y, size_t n, float t,
+                            float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    const float a = x ? x[idx] : 0.f;
+    out[idx] = a + (y[idx] - a) * t;
+}
+
+// tf.train.AdamOptimizer: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    const float g = gr[idx];
+    const float mm = m[idx] + (g - m[idx]) * (1.f - b1);
+    const float vv = v[idx] + (g * g - v[idx]) * (1.f - b2);
+    m[idx] = mm;
+    v[idx] = vv;
+    p[idx] -= lr_t * mm / (sqrtf(vv) + eps);
+}
+
+int fill_geom(ConvGeom& g, int n, int h, int w, int cin, int cout, int kh, int kw, int sh, int sw) {
+    g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw;
+    g.oh = (h + sh - 1) / sh;
+    g.ow = (w + sw - 1) / sw;
+    int ph = (g.oh - 1) * sh + kh - h; if (ph < 0) ph = 0;
+    int pw = (g.ow - 1) * sw + kw - w; if (pw < 0) pw = 0;
+    g.pt = ph / 2;
+    g.pl = pw / 2;
+    return 0;
+}
+
+}  // namespace
+
+#define MPG_GEOM_CHECK(NAME)                                                                                  \
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, NAME ": bad shape");                     \
+    MPG_REQUIRE(kh >= 1 && kw >= 1 && kh <= 16 && kw <= 16, NAME ": bad filter %dx%d", kh, kw);               \
+    MPG_REQUIRE(stride_h >= 1 && stride_w >= 1, NAME ": bad stride")
+
+extern "C" int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* dy,
+                                int cout, int kh, int kw, int stride_h, int stride_w, float wscale, float* dw) {
+    MPG_REQUIRE(x && dy && dw, "mpg_conv2d_wgrad: null pointer");
+    MPG_GEOM_CHECK("mpg_conv2d_wgrad");
+    ConvGeom g;
+    fill_geom(g, n, h, w, cin, cout, kh, kw, stride_h, stride_w);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad: memset");
+    const int mi = micro(cin), ni = micro(cout);
+#define MPG_WG(M, N) if (mi == M && ni == N) launch_wgrad<M, N>(s, x, dy, dw, g, wscale)
+    MPG_WG(1, 1); MPG_WG(1, 2); MPG_WG(1, 4); MPG_WG(1, 8);
+    MPG_WG(2, 1); MPG_WG(2, 2); MPG_WG(2, 4); MPG_WG(2, 8);
+    MPG_WG(4, 1); MPG_WG(4, 2); MPG_WG(4, 4); MPG_WG(4, 8);
+    MPG_WG(8, 1); MPG_WG(8, 2); MPG_WG(8, 4); MPG_WG(8, 8);
+#undef MPG_WG
+    MPG_LAUNCH_CHECK("wgrad_kernel");
+}
+
+extern "C" int mpg_conv2d_dgrad(mpg_stream_t stream, const float* dy, int n, int h, int w, int cin,
+                                const float* w_hwio, int cout, int kh, int kw, int stride_h, int stride_w,
+                                float wscale, float* dx) {
+    MPG_REQUIRE(dy && w_hwio && dx, "mpg_conv2d_dgrad: null pointer");
+    MPG_GEOM_CHECK("mpg_conv2d_dgrad");
+    ConvGeom g;
+    fill_geom(g, n, h, w, cin, cout, kh, kw, stride_h, stride_w);
+    const size_t total = (size_t)n * h * w * cin;
+    hipLaunchKernelGGL(dgrad_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, w_hwio, dx, g,
+                       wscale);
+    MPG_LAUNCH_CHECK("dgrad_kernel");
+}
+
+extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out) {
+    MPG_REQUIRE(x && out, "mpg_channel_sum: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_channel_sum: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_channel_sum: memset");
+    launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, out, nullptr);
+    MPG_LAUNCH_CHECK("chan_sum_kernel");
+}
+
+extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
+                                const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
+                                float* batch_var) {
+    MPG_REQUIRE(x && gamma && beta && y && batch_mean && batch_var, "mpg_bn_train_fwd: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_fwd: bad shape");
+    MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_bn_train_fwd: bad activation %d", act);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(batch_mean, 0, (size_t)c * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)c * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
+    const float inv_n = 1.f / (float)npix;
+    launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, nullptr);
+    launch_chan_sum<1>(s, x, nullptr, npix, c, batch_mean, nullptr, inv_n, 0.f, batch_var, nullptr);
+    hipLaunchKernelGGL(scale_vec_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, c, inv_n);
+    hipLaunchKernelGGL(scale_vec_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_var, c, inv_n);
+    const size_t total = npix * c;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
+                       gamma, beta, eps, act, leak, y);
+    MPG_LAUNCH_CHECK("bn_train_fwd");
+}
+
+extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
+                                const float* batch_mean, const float* batch_var, const float* gamma, float eps,
+                                float* dx, float* dgamma, float* dbeta) {
+    MPG_REQUIRE(dy && x && batch_mean && batch_var && gamma && dx && dgamma && dbeta,
+                "mpg_bn_train_bwd: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
+    launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
+    const size_t total = npix * c;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, dy, x, total, c, batch_mean,
+                       batch_var, gamma, dgamma, dbeta, eps, 1.f / (float)npix, dx);
+    MPG_LAUNCH_CHECK("bn_train_bwd");
+}
+
+extern "C" int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak,
+                           float* dx) {
+    MPG_REQUIRE(dy && y && dx, "mpg_act_bwd: null pointer");
+    MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_act_bwd: bad activation %d", act);
+    if (n == 0) return MPG_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx);
+    MPG_LAUNCH_CHECK("act_bwd_kernel");
+}
+
+extern "C" int mpg_pixel_norm_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c, float eps,
+                                  float* dx) {
+    MPG_REQUIRE(dy && x && dx, "mpg_pixel_norm_bwd: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_pixel_norm_bwd: bad shape");
+    hipLaunchKernelGGL(pixel_norm_bwd_kernel, dim3(grid_for(npix)), dim3(BLK), 0, (hipStream_t)stream, dy, x, npix, c,
+                       eps, dx);
+    MPG_LAUNCH_CHECK("pixel_norm_bwd_kernel");
+}
+
+extern "C" int mpg_resize_nearest_bwd(mpg_stream_t stream, const float* dy, int n, int oh, int ow, int c, float* dx,
+                                      int h, int w) {
+    MPG_REQUIRE(dy && dx, "mpg_resize_nearest_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && oh >= h && ow >= w, "mpg_resize_nearest_bwd: bad shape");
+    MPG_REQUIRE(oh % h == 0 && ow % w == 0, "mpg_resize_nearest_bwd: only integer factors (%dx%d -> %dx%d)", h, w, oh, ow);
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(resize_nearest_bwd_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, n, oh,
+                       ow, c, dx, h, w, 1.f);
+    MPG_LAUNCH_CHECK("resize_nearest_bwd_kernel");
+}
+
+extern "C" int mpg_avg_pool2_bwd(mpg_stream_t stream, const float* dy, int n, int h, int w, int c, float* dx) {
+    MPG_REQUIRE(dy && dx, "mpg_avg_pool2_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 2 && w >= 2 && c >= 1, "mpg_avg_pool2_bwd: bad shape");
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(avg_pool2_bwd_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, n, h, w, c,
+                       dx);
+    MPG_LAUNCH_CHECK("avg_pool2_bwd_kernel");
+}
+
+extern "C" int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, size_t n, float t, float* out) {
+    MPG_REQUIRE(y && out, "mpg_lerp: null pointer");
+    if (n == 0) return MPG_OK;
+    hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, x, y, n, t, out);
+    MPG_LAUNCH_CHECK("lerp_kernel");
+}
+
+extern "C" int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, size_t n,
+                             float lr_t, float beta1, float beta2, float eps) {
+    MPG_REQUIRE(p && grad && m && v, "mpg_adam_step: null pointer");
+    if (n == 0) return MPG_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, p, grad, m, v, n, lr_t,
+                       beta1, beta2, eps);
+    MPG_LAUNCH_CHECK("adam_kernel");
+}

@@ -1,0 +1,443 @@
+"""Training step of the 4x multi-pass GAN on the HIP kernels.
+
+The reference builds one TF graph and lets ``tf.gradients`` + ``AdamOptimizer.minimize`` walk it
+(multipassGAN-4x.py:728-902, training loop :1300-1360).  Here the same ``graph`` nodes are executed
+eagerly by ``TrainSession``; every layer is a ``torch.autograd.Function`` whose forward AND backward
+are kernels of libmpgan_hip.so (conv forward + data gradient on the MFMA kernel, weight gradient,
+batch-norm statistics, activation / resize / pool / pixel-norm backward).  torch supplies the tape,
+views (reshape / concat / slice), the scalar loss reductions and device memory, as north_star puts
+the losses and optimiser bookkeeping host/PyTorch side; the Adam update itself is ``mpg_adam_step``
+with TensorFlow's epsilon placement.
+"""
+import math
+
+import torch
+
+from . import _lib, ops, train_ops
+from . import graph as G
+
+TRAINABLE_KINDS = ("weight", "bias", "gamma", "beta")
+
+
+def _mfma_fwd_ok(kh, kw, cout, stride):
+    return stride == (1, 1) and kh <= 7 and kw <= 7 and cout <= 128
+
+
+def _mfma_dgrad_ok(kh, kw, cin, stride):
+    return stride == (1, 1) and kh % 2 == 1 and kw % 2 == 1 and kh <= 7 and kw <= 7 and cin <= 128
+
+
+class ConvLayerFn(torch.autograd.Function):
+    """act(bn_train?(conv2d_SAME(x, W * wscale) + b)) as GAN.convolutional_layer builds it
+    (GAN.py:80-119); one fused conv launch (+ the batch-statistics passes when BN is on)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, cfg):
+        stride, wscale, act, leak = cfg["stride"], cfg["wscale"], cfg["act"], cfg["leak"]
+        kh, kw, cin, cout = w.shape
+        x = x.contiguous()
+        bn = gamma is not None
+        conv_act = None if bn else act
+        if _mfma_fwd_ok(kh, kw, cout, stride):
+            pk = ops.pack_conv_weights(w.detach().contiguous(), wscale=wscale, prec=cfg["prec"])
+            lin = ops.conv2d_fused([ops.Segment(x, pk)], (x.shape[1], x.shape[2]), bias=b, act=conv_act, leak=leak)
+        else:
+            lin = ops.conv2d_direct(x, w.detach().contiguous(), stride, wscale, None, b, conv_act, leak)
+        if bn:
+            y, mean, var = train_ops.bn_train_fwd(lin, gamma, beta, cfg["eps"], act, leak)
+            cfg["batch_stats"] = (mean, var)
+            ctx.save_for_backward(x, w, lin, mean, var, gamma, y)
+        else:
+            y = lin
+            ctx.save_for_backward(x, w, y)
+        ctx.cfg, ctx.bn, ctx.has_bias = cfg, bn, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg = ctx.cfg
+        stride, wscale, act, leak = cfg["stride"], cfg["wscale"], cfg["act"], cfg["leak"]
+        if ctx.bn:
+            x, w, lin, mean, var, gamma, y = ctx.saved_tensors
+        else:
+            x, w, y = ctx.saved_tensors
+        kh, kw, cin, cout = w.shape
+        d = dy.contiguous()
+        if act is not None:
+            d = train_ops.act_bwd(d, y, act, leak)
+        dgamma = dbeta = None
+        if ctx.bn:
+            d, dgamma, dbeta = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"])
+        db = train_ops.channel_sum(d) if ctx.has_bias else None
+        dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale) if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _mfma_dgrad_ok(kh, kw, cin, stride):
+                wt = w.detach().flip(0, 1).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin], taps mirrored
+                pk = ops.pack_conv_weights(wt, wscale=wscale, prec=cfg["prec"])
+                dx = ops.conv2d_fused([ops.Segment(d, pk)], (x.shape[1], x.shape[2]))
+            else:
+                dx = train_ops.conv2d_dgrad(d, w.detach(), (x.shape[1], x.shape[2]), stride, wscale)
+        return dx, dw, db, dgamma, dbeta, None
+
+
+class ActFn(torch.autograd.Function):
+    """act(a [+ b]) (tf.nn.relu(tf.add(B, s)), multipassGAN-4x.py:523)"""
+
+    @staticmethod
+    def forward(ctx, a, b, act, leak):
+        y = ops.add_act(a.contiguous(), b.contiguous() if b is not None else None, act, leak)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.leak, ctx.two = act, leak, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        d = train_ops.act_bwd(dy, y, ctx.act, ctx.leak) if ctx.act is not None else dy
+        return d, (d if ctx.two else None), None, None
+
+
+class ResizeNearestFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.resize_nearest(x.contiguous(), oh, ow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return train_ops.resize_nearest_bwd(dy, *ctx.hw), None, None
+
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.avg_pool2(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return train_ops.avg_pool2_bwd(dy, *ctx.hw)
+
+
+class PixelNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return ops.pixel_norm(x, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return train_ops.pixel_norm_bwd(dy, x, ctx.eps), None
+
+
+class LerpFn(torch.autograd.Function):
+    """lerp(x, y, t) (multipassGAN-8x.py:598-599); x may be None (tf.zeros_like)"""
+
+    @staticmethod
+    def forward(ctx, x, y, t):
+        ctx.t = min(max(float(t), 0.0), 1.0)
+        ctx.has_x = x is not None
+        return train_ops.lerp(x, y, ctx.t)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dxy = train_ops.lerp(None, dy, ctx.t)
+        dx = train_ops.lerp(None, dy, 1.0 - ctx.t) if ctx.has_x else None
+        return dx, dxy, None
+
+
+class TrainSession(object):
+    """Eager, differentiable evaluation of ``graph`` nodes; parameters are leaf tensors keyed by
+    the TF variable path.  ``run(fetches, feeds)`` returns torch tensors that carry the tape."""
+
+    def __init__(self, variables, graph=None, prec=ops.PREC_F16X3, bn_decay=0.999, device="cuda:0"):
+        self.graph = graph or G.get_default_graph()
+        self.vars = variables
+        self.prec = prec
+        self.bn_decay = bn_decay
+        self.device = torch.device(device)
+        self.params = {}
+        self._bn_updates = []
+
+    def parameters(self):
+        """name -> leaf tensor for every variable of the graph (trainable ones require grad)"""
+        self.vars.ensure(self.graph)
+        for name, spec in self.graph.variables.items():
+            if name not in self.params:
+                t = self.vars.get(name).detach().clone().contiguous()
+                t.requires_grad_(spec.kind in TRAINABLE_KINDS)
+                self.params[name] = t
+        return self.params
+
+    def trainable(self, tag):
+        """tf.trainable_variables() filtered like the reference: `tag in var.name` (multipassGAN-4x.py:780-784)"""
+        ps = self.parameters()
+        return {n: p for n, p in ps.items() if p.requires_grad and tag in n}
+
+    def sync_to_store(self):
+        for name, p in self.params.items():
+            self.vars.values[name] = p.detach().clone()
+        self.vars.version += 1
+
+    # ------------------------------------------------------------------ evaluation
+    def run(self, fetches, feeds):
+        _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.MpgError("no GPU visible: the training step has no CPU fallback")
+        self.parameters()
+        env = {}
+        for node, t in feeds.items():
+            env[node.id] = torch.as_tensor(t, dtype=torch.float32, device=self.device)
+        users = self._count_users(fetches)
+        self._bn_updates = []
+        outs = [self._eval(f, env, users) for f in fetches]
+        # UPDATE_OPS of tf.contrib.layers.batch_norm run with the step (multipassGAN-4x.py:773-776,889-899)
+        with torch.no_grad():
+            for mm, mv, mean, var in self._bn_updates:
+                mm.mul_(self.bn_decay).add_(mean, alpha=1.0 - self.bn_decay)
+                mv.mul_(self.bn_decay).add_(var, alpha=1.0 - self.bn_decay)
+        return outs
+
+    def _count_users(self, fetches):
+        users, seen, stack = {}, set(), list(fetches)
+        for f in fetches:
+            users[f.id] = users.get(f.id, 0) + 1
+        while stack:
+            n = stack.pop()
+            if n.id in seen:
+                continue
+            seen.add(n.id)
+            for i in n.inputs:
+                users[i.id] = users.get(i.id, 0) + 1
+                stack.append(i)
+        return users
+
+    def _layer_chain(self, n, users):
+        """n = [act](batch_norm?(bias_add?(conv2d|matmul))) with single-use links -> (conv, bias, bn, act, leak)"""
+        cur, act, leak = n, None, 0.2
+        if cur.op == "act":
+            nxt = cur.inputs[0]
+            if users.get(nxt.id, 0) != 1 or nxt.op not in ("batch_norm", "bias_add", "conv2d", "matmul"):
+                return None
+            act, leak = cur.attrs["act"], cur.attrs.get("leak", 0.2)
+            cur = nxt
+        bn = bias = None
+        if cur.op == "batch_norm":
+            bn = cur
+            if users.get(cur.inputs[0].id, 0) != 1:
+                return None
+            cur = cur.inputs[0]
+        if cur.op == "bias_add":
+            bias = cur
+            if users.get(cur.inputs[0].id, 0) != 1:
+                return None
+            cur = cur.inputs[0]
+        if cur.op not in ("conv2d", "matmul"):
+            return None
+        return cur, bias, bn, act, leak
+
+    def _eval(self, n, env, users):
+        if n.id in env:
+            return env[n.id]
+        v = self._compute(n, env, users)
+        env[n.id] = v
+        return v
+
+    def _compute(self, n, env, users):
+        op = n.op
+        ev = lambda m: self._eval(m, env, users)   # noqa: E731
+        if op == "placeholder":
+            raise G.GraphError("placeholder %r was not fed" % (n,))
+        if op == "variable":
+            return self.params[n.attrs["var"]]
+        if op in ("act", "batch_norm", "bias_add", "conv2d", "matmul"):
+            chain = self._layer_chain(n, users)
+            if chain is not None:
+                return self._conv_layer(chain, ev)
+            if op == "act":
+                x = n.inputs[0]
+                if x.op == "add" and users.get(x.id, 0) == 1:
+                    return ActFn.apply(ev(x.inputs[0]), ev(x.inputs[1]), n.attrs["act"], n.attrs.get("leak", 0.2))
+                return ActFn.apply(ev(x), None, n.attrs["act"], n.attrs.get("leak", 0.2))
+            raise G.GraphError("training: no lowering for %r" % (n,))
+        if op == "add":
+            return ActFn.apply(ev(n.inputs[0]), ev(n.inputs[1]), None, 0.2)
+        if op == "reshape":
+            return ev(n.inputs[0]).reshape(n.attrs["target"])
+        if op == "concat":
+            return torch.cat([ev(i) for i in n.inputs], dim=-1)
+        if op == "slice":
+            b, s = n.attrs["begin"], n.attrs["size"]
+            return ev(n.inputs[0])[..., b:b + s]
+        if op == "slice_flat":
+            x = ev(n.inputs[0])
+            return x.reshape(x.shape[0], -1)[:, :n.attrs["count"]]
+        if op == "pixel_norm":
+            return PixelNormFn.apply(ev(n.inputs[0]), n.attrs["eps"])
+        if op == "avg_pool":
+            return AvgPoolFn.apply(ev(n.inputs[0]))
+        if op == "lerp":
+            x = ev(n.inputs[0]) if n.inputs[0] is not None else None
+            return LerpFn.apply(x, ev(n.inputs[1]), n.attrs["t"])
+        if op == "resize":
+            x = ev(n.inputs[0])
+            if n.attrs["method"] == 1:
+                return ResizeNearestFn.apply(x, n.attrs["oh"], n.attrs["ow"])
+            if x.requires_grad:
+                raise NotImplementedError("gradient of bilinear / bicubic resize (only applied to network inputs)")
+            return ops.resize_images(x.contiguous(), n.attrs["oh"], n.attrs["ow"], n.attrs["method"])
+        raise G.GraphError("training: no lowering for %r" % (n,))
+
+    def _conv_layer(self, chain, ev):
+        conv, bias, bn, act, leak = chain
+        x = ev(conv.inputs[0])
+        w = self.params[conv.inputs[1].attrs["var"]]
+        b = self.params[bias.inputs[1].attrs["var"]] if bias is not None else None
+        is_fc = conv.op == "matmul"
+        if is_fc:
+            nrow = x.shape[0]
+            x = x.reshape(nrow, 1, 1, -1)
+            w4 = w.reshape(1, 1, w.shape[0], w.shape[1])
+            stride = (1, 1)
+        else:
+            w4, stride = w, tuple(conv.attrs["stride"])
+        cfg = {"stride": stride, "wscale": conv.attrs["wscale"], "act": act, "leak": leak, "prec": self.prec,
+               "eps": bn.attrs["eps"] if bn is not None else 0.0}
+        gamma = beta = None
+        if bn is not None:
+            if not bn.attrs["training"]:
+                raise G.GraphError("TrainSession needs batch_norm(training=True) nodes (build the nets with train=True)")
+            gamma = self.params[bn.inputs[1].attrs["var"]]
+            beta = self.params[bn.inputs[2].attrs["var"]]
+        y = ConvLayerFn.apply(x, w4, b, gamma, beta, cfg)
+        if bn is not None:
+            mean, var = cfg["batch_stats"]
+            self._bn_updates.append((self.params[bn.inputs[3].attrs["var"]], self.params[bn.inputs[4].attrs["var"]],
+                                     mean, var))
+        return y.reshape(y.shape[0], -1) if is_fc else y
+
+
+class AdamTF(object):
+    """tf.train.AdamOptimizer(lr, beta1, beta2=0.999, epsilon=1e-8) over a set of leaf tensors, one
+    flat fp32 buffer per optimiser: p -= lr_t * m / (sqrt(v) + eps) (``mpg_adam_step``)."""
+
+    def __init__(self, params, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8):
+        self.names = sorted(params)
+        self.params = [params[n] for n in self.names]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat[off:off + k].view(p.shape)       # parameters alias the flat buffer
+                off += k
+        self.lr, self.b1, self.b2, self.eps, self.t = lr, beta1, beta2, eps, 0
+
+    def step(self, grads, lr=None):
+        """grads: list aligned with self.params (None = zero gradient, as tf treats unconnected variables)"""
+        off = 0
+        for p, g in zip(self.params, grads):
+            k = p.numel()
+            if g is None:
+                self.grad[off:off + k].zero_()
+            else:
+                self.grad[off:off + k].copy_(g.reshape(-1))
+            off += k
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        train_ops.adam_step(self.flat, self.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps)
+
+
+def sigmoid_ce(logits, label):
+    """tf.nn.sigmoid_cross_entropy_with_logits, mean over the batch: max(x,0) - x*z + log(1+exp(-|x|))"""
+    return (torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))).mean()
+
+
+class Trainer4x(object):
+    """The GAN training iteration of multipassGAN-4x.py (graph :728-768,880-902, loop :1317-1356):
+    ``discRuns`` discriminator updates then ``genRuns`` generator updates on tile batches, spatial
+    discriminator with feature losses, sigmoid cross entropy + lambda * L1 (+ lambda2 * layer loss)."""
+
+    def __init__(self, tileSizeLow=16, upRes=4, n_inputChannels=4, batch_norm=True, upsampling_mode=2, device="cuda:0",
+                 learning_rate=2e-4, beta1=0.5, lambda_l1=1.0, lambda2=0.0, lambda2_l=(1.0, 1.0, 1.0, 1.0),
+                 weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777):
+        from . import nets
+        from .session import VariableStore
+        self.tileSizeLow, self.upRes, self.C = tileSizeLow, upRes, n_inputChannels
+        self.tileSizeHigh = tileSizeLow * upRes
+        self.n_input = tileSizeLow * tileSizeLow * n_inputChannels
+        if upsampling_mode in (1, 3):
+            self.n_input = self.tileSizeHigh * self.tileSizeHigh * n_inputChannels
+        self.n_output = self.tileSizeHigh * self.tileSizeHigh
+        self.k, self.k2, self.k2_l, self.weight_dld = lambda_l1, lambda2, lambda2_l, weight_dld
+        g = G.reset_default_graph()
+        self.graph = g
+        self.x = G.placeholder([None, self.n_input], name="x")
+        self.x_disc = G.placeholder([None, self.n_input], name="x_disc")
+        self.y = G.placeholder([None, self.n_output], name="y")
+        self.gen_part = nets.gen_resnet(self.x, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
+                                        use_batch_norm=batch_norm, train=True)
+        dkw = dict(tileSizeLow=tileSizeLow, upRes=upRes, n_input=self.n_input, n_inputChannels=n_inputChannels,
+                   upsampling_mode=upsampling_mode, use_batch_norm=batch_norm, train=True, bn_decay=bn_decay)
+        self.disc = nets.disc_binclass(self.x_disc, self.y, **dkw)
+        self.gen = nets.disc_binclass(self.x_disc, self.gen_part, reuse=True, **dkw)
+        self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, bn_decay=bn_decay,
+                                 device=device)
+        self.g_var = self.sess.trainable("g_")
+        self.d_var = self.sess.trainable("d_")
+        self.opt_d = AdamTF(self.d_var, learning_rate, beta1)
+        self.opt_g = AdamTF(self.g_var, learning_rate, beta1)
+
+    def losses(self, batch_xs, batch_ys):
+        """-> dict of the loss tensors of multipassGAN-4x.py:744-768 (one forward of G, D(real), D(fake))"""
+        feeds = {self.x: batch_xs, self.x_disc: batch_xs, self.y: batch_ys}
+        fetch = [self.gen_part] + list(self.disc) + list(self.gen)
+        out = self.sess.run(fetch, feeds)
+        gen_part, (disc, dy1, dy2, dy3, dy4), (gen, gy1, gy2, gy3, gy4) = out[0], out[1:6], out[6:11]
+        y = torch.as_tensor(batch_ys, dtype=torch.float32, device=gen_part.device).reshape(gen_part.shape)
+        ones, zeros = torch.ones_like(disc), torch.zeros_like(disc)
+        L = {}
+        L["disc_loss_disc"] = sigmoid_ce(disc, ones)
+        L["disc_loss_gen"] = sigmoid_ce(gen, zeros)
+        layer = 0.0
+        for kf, a, b in zip(self.k2_l, (dy1, dy2, dy3, dy4), (gy1, gy2, gy3, gy4)):
+            layer = layer + kf * 0.5 * ((a - b) ** 2).sum()          # tf.nn.l2_loss
+        L["disc_loss_layer"] = layer
+        L["disc_loss"] = L["disc_loss_disc"] * self.weight_dld + L["disc_loss_gen"]
+        L["gen_loss"] = sigmoid_ce(gen, ones)
+        L["gen_l2_loss"] = 0.5 * ((y - gen_part) ** 2).sum()
+        L["gen_l1_loss"] = (y - gen_part).abs().mean()
+        L["gen_loss_complete"] = L["gen_loss"] + L["gen_l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
+        L["gen_part"] = gen_part
+        return L
+
+    def disc_step(self, batch_xs, batch_ys):
+        L = self.losses(batch_xs, batch_ys)
+        grads = torch.autograd.grad(L["disc_loss"], self.opt_d.params, allow_unused=True)
+        self.opt_d.step(grads)
+        return L
+
+    def gen_step(self, batch_xs, batch_ys):
+        L = self.losses(batch_xs, batch_ys)
+        grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
+        self.opt_g.step(grads)
+        return L
+
+    def train_step(self, batch_xs, batch_ys, discRuns=1, genRuns=1):
+        """one iteration of the reference loop (:1317-1356): returns (disc_loss, gen_loss_complete) as floats"""
+        for _ in range(discRuns):
+            Ld = self.disc_step(batch_xs, batch_ys)
+        for _ in range(genRuns):
+            Lg = self.gen_step(batch_xs, batch_ys)
+        return Ld["disc_loss"], Lg["gen_loss_complete"]

@@ -1,0 +1,136 @@
+"""Thin wrappers over the training entries of the C ABI (include/mpgan.h, "Training step").
+fp32 NHWC GPU tensors in, fp32 GPU tensors out; no CPU fallback."""
+import torch
+
+from . import _lib
+from .ops import _dev, _ptr, _stream
+
+
+def _cont(t, name):
+    return _dev(t.contiguous(), name)
+
+
+def conv2d_wgrad(x, dy, kh, kw, stride=(1, 1), wscale=1.0):
+    """dL/dW (HWIO, W stored unscaled: GAN.py:664-668) of y = conv2d_SAME(x, W * wscale)."""
+    lib = _lib.load()
+    x, dy = _cont(x, "x"), _cont(dy, "dy")
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    sh, sw = stride
+    if tuple(dy.shape[:3]) != (n, -(-h // sh), -(-w // sw)):
+        raise _lib.MpgError("conv2d_wgrad: dy shape %s does not match x %s stride %s" % (tuple(dy.shape), tuple(x.shape), stride))
+    dw = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_conv2d_wgrad(_stream(), _ptr(x), n, h, w, cin, _ptr(dy), cout, kh, kw, sh, sw, float(wscale),
+                                    _ptr(dw)), "mpg_conv2d_wgrad")
+    return dw
+
+
+def conv2d_dgrad(dy, w_hwio, in_hw, stride=(1, 1), wscale=1.0):
+    """dL/dx of y = conv2d_SAME(x, W * wscale) for x of spatial size in_hw."""
+    lib = _lib.load()
+    dy, w = _cont(dy, "dy"), _cont(w_hwio, "w_hwio")
+    kh, kw, cin, cout = w.shape
+    n = dy.shape[0]
+    h, wd = in_hw
+    sh, sw = stride
+    if tuple(dy.shape) != (n, -(-h // sh), -(-wd // sw), cout):
+        raise _lib.MpgError("conv2d_dgrad: dy shape %s does not match input %s stride %s" % (tuple(dy.shape), in_hw, stride))
+    dx = torch.empty((n, h, wd, cin), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mpg_conv2d_dgrad(_stream(), _ptr(dy), n, h, wd, cin, _ptr(w), cout, kh, kw, sh, sw, float(wscale),
+                                    _ptr(dx)), "mpg_conv2d_dgrad")
+    return dx
+
+
+def channel_sum(x):
+    lib = _lib.load()
+    x = _cont(x, "x")
+    c = x.shape[-1]
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_channel_sum(_stream(), _ptr(x), x.numel() // c, c, _ptr(out)), "mpg_channel_sum")
+    return out
+
+
+def bn_train_fwd(x, gamma, beta, eps=1e-3, act=None, leak=0.2):
+    """-> (y, batch_mean, batch_var[biased])"""
+    lib = _lib.load()
+    x = _cont(x, "x")
+    c = x.shape[-1]
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    var = torch.empty((c,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_bn_train_fwd(_stream(), _ptr(x), x.numel() // c, c, _ptr(_cont(gamma, "gamma")),
+                                    _ptr(_cont(beta, "beta")), float(eps), _lib.act_id(act), leak, _ptr(y), _ptr(mean),
+                                    _ptr(var)), "mpg_bn_train_fwd")
+    return y, mean, var
+
+
+def bn_train_bwd(dy, x, mean, var, gamma, eps=1e-3):
+    """-> (dx, dgamma, dbeta); dy is the gradient at the normalised (pre-activation) output"""
+    lib = _lib.load()
+    dy, x = _cont(dy, "dy"), _cont(x, "x")
+    c = x.shape[-1]
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_bn_train_bwd(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, _ptr(mean), _ptr(var),
+                                    _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta)),
+               "mpg_bn_train_bwd")
+    return dx, dgamma, dbeta
+
+
+def act_bwd(dy, y, act, leak=0.2):
+    lib = _lib.load()
+    dy, y = _cont(dy, "dy"), _cont(y, "y")
+    dx = torch.empty_like(dy)
+    _lib.check(lib.mpg_act_bwd(_stream(), _ptr(dy), _ptr(y), dy.numel(), _lib.act_id(act), leak, _ptr(dx)), "mpg_act_bwd")
+    return dx
+
+
+def pixel_norm_bwd(dy, x, eps=1e-8):
+    lib = _lib.load()
+    dy, x = _cont(dy, "dy"), _cont(x, "x")
+    c = x.shape[-1]
+    dx = torch.empty_like(x)
+    _lib.check(lib.mpg_pixel_norm_bwd(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, float(eps), _ptr(dx)),
+               "mpg_pixel_norm_bwd")
+    return dx
+
+
+def resize_nearest_bwd(dy, h, w):
+    lib = _lib.load()
+    dy = _cont(dy, "dy")
+    n, oh, ow, c = dy.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mpg_resize_nearest_bwd(_stream(), _ptr(dy), n, oh, ow, c, _ptr(dx), h, w), "mpg_resize_nearest_bwd")
+    return dx
+
+
+def avg_pool2_bwd(dy, h, w):
+    lib = _lib.load()
+    dy = _cont(dy, "dy")
+    n, _, _, c = dy.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mpg_avg_pool2_bwd(_stream(), _ptr(dy), n, h, w, c, _ptr(dx)), "mpg_avg_pool2_bwd")
+    return dx
+
+
+def lerp(x, y, t):
+    """x + (y - x) * clip(t, 0, 1) (multipassGAN-8x.py:598-599); x None = zeros_like(y)"""
+    lib = _lib.load()
+    y = _cont(y, "y")
+    x = _cont(x, "x") if x is not None else None
+    out = torch.empty_like(y)
+    t = min(max(float(t), 0.0), 1.0)
+    _lib.check(lib.mpg_lerp(_stream(), _ptr(x), _ptr(y), y.numel(), t, _ptr(out)), "mpg_lerp")
+    return out
+
+
+def adam_step(p, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
+    """in-place tf.train.AdamOptimizer update of the flat fp32 buffer p"""
+    lib = _lib.load()
+    for t, nm in ((p, "p"), (grad, "grad"), (m, "m"), (v, "v")):
+        _dev(t, nm)
+        if not t.is_contiguous():
+            raise _lib.MpgError("adam_step: %s must be contiguous" % nm)
+    _lib.check(lib.mpg_adam_step(_stream(), _ptr(p), _ptr(grad), _ptr(m), _ptr(v), p.numel(), float(lr_t), float(beta1),
+                                 float(beta2), float(eps)), "mpg_adam_step")

@@ -132,3 +132,17 @@ def test_fusion_plan(mpg):
     assert [(s["cin"], s["up_log2"]) for s in plan[0]["segments"]] == [(1, 0), (4, 3)]
     assert [(s["cin"], s["up_log2"], s["kernel"]) for s in plan[1]["segments"]] == [(16, 0, (5, 5)), (1, 0, (1, 1)), (4, 3, (1, 1))]
     assert plan[-1]["cout"] == 1 and plan[-1]["post_add"] is not None and plan[0]["pixel_norm"]
+
+
+def test_trainer_builds_on_cpu_and_refuses_to_run_without_gpu():
+    """graph construction and parameter grouping need no GPU; the step itself has no CPU fallback"""
+    import torch
+    from mpgan_amd import _lib
+    from mpgan_amd.train import Trainer4x
+    tr = Trainer4x(tileSizeLow=8, upRes=4, n_inputChannels=4, batch_norm=True)
+    assert len(tr.opt_g.names) == 4 * 3 * 2 + 3 * 3 * 2          # weights+biases of 12 convs, gamma+beta of 9
+    assert len(tr.opt_d.names) == 5 * 2 + 3 * 2
+    assert all("g_" in n for n in tr.opt_g.names) and all("d_" in n for n in tr.opt_d.names)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.MpgError):
+            tr.losses(np.zeros((2, 8 * 8 * 4), np.float32), np.zeros((2, 32 * 32), np.float32))

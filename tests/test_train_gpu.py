@@ -1,0 +1,264 @@
+"""Training-step kernels and the 4x GAN iteration against the float64 autograd restatement
+(oracle/train_ref.py).  Tolerances: fp32 kernels 1e-5 relative L2 (accumulation order differs);
+layers whose forward / data gradient run on the MFMA kernel at F16X3 2e-5; whole-network gradients
+1e-3 per tensor (ReLU gates of near-zero pre-activations may flip), 1e-4 on the losses."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import train_ref as TR
+from oracle.nets import ParamSource
+from oracle.ops import same_pad
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
+
+
+def ref_conv_grads(x, w, dy, stride, wscale):
+    """float64 autograd of tf.nn.conv2d SAME: x NHWC, w HWIO, dy NHWC -> (dx, dw)"""
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    wt = torch.tensor(w, dtype=torch.float64).requires_grad_(True)
+    _, pt, pb = same_pad(x.shape[1], w.shape[0], stride)
+    _, pl, pr = same_pad(x.shape[2], w.shape[1], stride)
+    y = F.conv2d(F.pad(xt, (pl, pr, pt, pb)), (wt * wscale).permute(3, 2, 0, 1).contiguous(), stride=stride)
+    y.backward(torch.tensor(dy, dtype=torch.float64).permute(0, 3, 1, 2))
+    return xt.grad.permute(0, 2, 3, 1).numpy(), wt.grad.numpy()
+
+
+GRAD_CASES = [
+    # n, h, w, cin, cout, k, stride
+    (2, 16, 16, 4, 8, 5, 1),
+    (2, 16, 16, 32, 128, 5, 1),
+    (1, 24, 20, 128, 128, 3, 1),
+    (3, 8, 8, 128, 32, 5, 1),
+    (2, 16, 16, 8, 1, 5, 1),
+    (2, 16, 16, 1, 2, 5, 1),
+    (2, 12, 12, 9, 17, 1, 1),
+    (2, 16, 16, 2, 32, 4, 2),
+    (2, 16, 16, 32, 64, 4, 2),
+    (2, 9, 7, 64, 128, 4, 2),
+    (2, 8, 8, 128, 256, 4, 1),
+    (4, 1, 1, 1024, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", GRAD_CASES)
+def test_conv_wgrad_dgrad(case):
+    from mpgan_amd import train_ops
+    n, h, w, cin, cout, k, s = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    oh, ow = -(-h // s), -(-w // s)
+    dy = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    wscale = float(np.float32(math.sqrt(2.0) / math.sqrt(k * k * cin)))
+    dx_ref, dw_ref = ref_conv_grads(x, wt, dy, s, wscale)
+    dw = train_ops.conv2d_wgrad(dev(x), dev(dy), k, k, (s, s), wscale).cpu().numpy()
+    dx = train_ops.conv2d_dgrad(dev(dy), dev(wt), (h, w), (s, s), wscale).cpu().numpy()
+    assert dw.shape == dw_ref.shape and dx.shape == dx_ref.shape
+    assert rel(dw, dw_ref) < 1e-5
+    assert rel(dx, dx_ref) < 1e-5
+
+
+@pytest.mark.parametrize("bn", [False, True])
+@pytest.mark.parametrize("case", [(2, 16, 16, 8, 32, 5, 1, "relu"), (2, 16, 16, 32, 8, 5, 1, None),
+                                  (2, 16, 16, 16, 16, 1, 1, "lrelu"), (2, 16, 16, 2, 32, 4, 2, "lrelu"),
+                                  (2, 8, 8, 128, 256, 4, 1, "lrelu")])
+def test_conv_layer_fn(case, bn):
+    """ConvLayerFn (fused forward, MFMA data gradient where the shape allows) vs float64 autograd"""
+    from mpgan_amd import ops
+    from mpgan_amd.train import ConvLayerFn
+    n, h, w, cin, cout, k, s, act = case
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(cout)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+    oh, ow = -(-h // s), -(-w // s)
+    dy = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    wscale = float(np.float32(math.sqrt(2.0) / math.sqrt(k * k * cin)))
+    # reference
+    p = {"L/weight": torch.tensor(wt, dtype=torch.float64, requires_grad=True),
+         "L/bias": torch.tensor(b, dtype=torch.float64, requires_grad=True),
+         "L/gamma": torch.tensor(gamma, dtype=torch.float64, requires_grad=True),
+         "L/beta": torch.tensor(beta, dtype=torch.float64, requires_grad=True)}
+    xr = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2).requires_grad_(True)
+    gain = wscale * math.sqrt(k * k * cin)
+    yr, _ = TR.conv_layer(p, "L", xr, act, s, bn, gain=gain)
+    yr.backward(torch.tensor(dy, dtype=torch.float64).permute(0, 3, 1, 2))
+    # HIP
+    xt = dev(x).requires_grad_(True)
+    wd, bd, gd, bed = [dev(a).requires_grad_(True) for a in (wt, b, gamma, beta)]
+    cfg = {"stride": (s, s), "wscale": wscale, "act": act, "leak": 0.2, "prec": ops.PREC_F16X3, "eps": 1e-3}
+    y = ConvLayerFn.apply(xt, wd, bd, gd if bn else None, bed if bn else None, cfg)
+    y.backward(dev(dy))
+    tol = 2e-5
+    assert rel(y.detach().cpu().numpy(), yr.detach().permute(0, 2, 3, 1).numpy()) < tol
+    assert rel(xt.grad.cpu().numpy(), xr.grad.permute(0, 2, 3, 1).numpy()) < tol
+    assert rel(wd.grad.cpu().numpy(), p["L/weight"].grad.numpy()) < tol
+    if bn:
+        assert rel(gd.grad.cpu().numpy(), p["L/gamma"].grad.numpy()) < tol
+        assert rel(bed.grad.cpu().numpy(), p["L/beta"].grad.numpy()) < tol
+        # the bias gradient under batch norm is zero up to rounding
+        assert np.abs(bd.grad.cpu().numpy()).max() < 1e-3 * np.abs(dy).sum() / cout
+        mean, var = cfg["batch_stats"]
+        lin = TR.conv2d_same(xr, p["L/weight"] * wscale, s) + p["L/bias"].view(1, -1, 1, 1)
+        assert rel(mean.cpu().numpy(), lin.mean(dim=(0, 2, 3)).detach().numpy()) < tol
+        assert rel(var.cpu().numpy(), lin.var(dim=(0, 2, 3), unbiased=False).detach().numpy()) < 1e-4
+    else:
+        assert rel(bd.grad.cpu().numpy(), p["L/bias"].grad.numpy()) < tol
+
+
+def test_elementwise_backward():
+    from mpgan_amd import train_ops
+    from mpgan_amd.train import ActFn, AvgPoolFn, LerpFn, PixelNormFn, ResizeNearestFn
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 6, 10, 12)).astype(np.float32)
+    x2 = rng.standard_normal((2, 6, 10, 12)).astype(np.float32)
+
+    def check(fn_hip, fn_ref, *arrs, tol=1e-6):
+        th = [dev(a).requires_grad_(True) for a in arrs]
+        tr = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in arrs]
+        yh, yr = fn_hip(*th), fn_ref(*tr)
+        g = rng.standard_normal(tuple(yr.shape)).astype(np.float32)
+        yh.backward(dev(g))
+        yr.backward(torch.tensor(g, dtype=torch.float64))
+        assert rel(yh.detach().cpu().numpy(), yr.detach().numpy()) < tol
+        for a, b in zip(th, tr):
+            assert rel(a.grad.cpu().numpy(), b.grad.numpy()) < tol
+
+    check(lambda a, b: ActFn.apply(a, b, "relu", 0.2), lambda a, b: torch.relu(a + b), x, x2)
+    check(lambda a: ActFn.apply(a, None, "lrelu", 0.2), lambda a: TR.lrelu(a), x)
+    check(lambda a: ActFn.apply(a, None, "tanh", 0.2), lambda a: torch.tanh(a), x)
+    check(lambda a, b: ActFn.apply(a, b, None, 0.2), lambda a, b: a + b, x, x2)
+    check(lambda a: PixelNormFn.apply(a, 1e-8), lambda a: a * torch.rsqrt((a * a).mean(dim=3, keepdim=True) + 1e-8), x)
+    check(lambda a: ResizeNearestFn.apply(a, 24, 20),
+          lambda a: a.repeat_interleave(4, 1).repeat_interleave(2, 2), x)
+    check(lambda a: AvgPoolFn.apply(a),
+          lambda a: F.avg_pool2d(a.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1), x)
+    check(lambda a, b: LerpFn.apply(a, b, 0.3), lambda a, b: a + (b - a) * 0.3, x, x2)
+    check(lambda b: LerpFn.apply(None, b, 1.7), lambda b: b * 1.0, x2)
+    s = train_ops.channel_sum(dev(x)).cpu().numpy()
+    assert rel(s, x.reshape(-1, 12).astype(np.float64).sum(0)) < 1e-6
+
+
+def test_adam_step_matches_tf_formula():
+    from mpgan_amd import train_ops
+    rng = np.random.default_rng(9)
+    n = 10007
+    p = rng.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pd, md, vd = dev(p), dev(m), dev(v)
+    pr, mr, vr = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for t in range(1, 4):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 1, n)).astype(np.float32)
+        lr_t = 2e-4 * math.sqrt(1 - 0.999 ** t) / (1 - 0.5 ** t)
+        train_ops.adam_step(pd, dev(g), md, vd, lr_t, 0.5, 0.999, 1e-8)
+        pr, mr, vr = TR.adam_tf(pr, g.astype(np.float64), mr, vr, t)
+    e_p = np.abs(pd.cpu().numpy() - pr).max()
+    e_m, e_v = rel(md.cpu().numpy(), mr), rel(vd.cpu().numpy(), vr)
+    assert e_p < 1e-6 and e_m < 1e-6 and e_v < 1e-6, (e_p, e_m, e_v)
+
+
+BN_BIASES = {"generator/g_c%s%d/bias" % (k, i) for k in "AB" for i in range(3)} | \
+    {"generator/g_s%d/bias" % i for i in range(3)} | {"discriminator/d_c%d/bias" % i for i in (2, 3, 4)}
+
+
+def _trainer_and_oracle(tile, C, batch, bn, seed=5):
+    from mpgan_amd.train import Trainer4x
+    tr = Trainer4x(tileSizeLow=tile, upRes=4, n_inputChannels=C, batch_norm=bn, device=DEV, seed=seed)
+    ps = ParamSource(seed=seed)
+    params = {}
+    for name, spec in tr.graph.variables.items():
+        params[name] = ps.get(name, spec.shape, spec.kind)
+    with torch.no_grad():
+        for name, t in tr.sess.params.items():
+            t.copy_(dev(params[name]))
+    rng = np.random.default_rng(77)
+    xs = rng.random((batch, tile * tile * C)).astype(np.float32)
+    ys = rng.random((batch, (tile * 4) ** 2)).astype(np.float32)
+    return tr, TR.to_params(params), xs, ys
+
+
+@pytest.mark.parametrize("C,bn", [(4, True), (1, True), (4, False)])
+def test_gan4x_losses_and_gradients(C, bn):
+    tile, batch = 8, 4
+    tr, p, xs, ys = _trainer_and_oracle(tile, C, batch, bn)
+    L = tr.losses(xs, ys)
+    Lr = TR.losses_4x(p, xs, ys, tile, 4, C, batch_norm=bn)
+    for k in ("disc_loss", "gen_loss", "gen_l1_loss", "gen_l2_loss", "disc_loss_layer", "gen_loss_complete"):
+        a, b = float(L[k].detach()), float(Lr[k].detach())
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
+    assert rel(L["gen_part"].detach().cpu().numpy().reshape(batch, -1), Lr["gen_part"].detach().numpy().reshape(batch, -1)) < 1e-4
+    gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+    rd = TR.grads(Lr["disc_loss"], p, "d_")
+    rg = TR.grads(Lr["gen_loss_complete"], p, "g_")
+    assert sorted(rd) == tr.opt_d.names and sorted(rg) == tr.opt_g.names
+    worst = 0.0
+    for names, got, want in ((tr.opt_d.names, gd, rd), (tr.opt_g.names, gg, rg)):
+        tot_d = tot_r = 0.0
+        for nme, g in zip(names, got):
+            w = want[nme]
+            gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
+            if bn and nme in BN_BIASES:
+                # bias under batch norm: exact gradient is 0, both sides hold rounding noise only
+                assert np.abs(gnp).max() < 1e-4
+                continue
+            r = rel(gnp, w)
+            worst = max(worst, r)
+            assert r < 1e-3, (nme, r)
+            tot_d += float(((gnp - w) ** 2).sum())
+            tot_r += float((w ** 2).sum())
+        assert math.sqrt(tot_d / tot_r) < 2e-4
+    print("worst per-tensor gradient error", worst)
+
+
+def test_gan4x_train_step_updates_parameters():
+    tile, C, batch = 8, 4, 4
+    tr, p, xs, ys = _trainer_and_oracle(tile, C, batch, True)
+    before = {n: t.detach().cpu().numpy().copy() for n, t in tr.sess.params.items()}
+    Lr = TR.losses_4x(p, xs, ys, tile, 4, C)
+    rd = TR.grads(Lr["disc_loss"], p, "d_")
+    stats = {}
+    TR.losses_4x(p, xs, ys, tile, 4, C, stats=stats)
+    Ld = tr.disc_step(xs, ys)
+    lr = 2e-4
+    bad = tot = 0
+    for nme in tr.opt_d.names:
+        delta = tr.sess.params[nme].detach().cpu().numpy() - before[nme]
+        want, _, _ = TR.adam_tf(np.zeros_like(rd[nme]), rd[nme], np.zeros_like(rd[nme]), np.zeros_like(rd[nme]), 1)
+        assert np.abs(delta).max() <= lr * 1.001
+        strong = np.abs(rd[nme]) > 1e-6 * np.abs(rd[nme]).max()
+        bad += int((np.abs(delta - want)[strong] > 0.05 * lr).sum())
+        tot += int(strong.sum())
+    assert bad <= 0.002 * tot, (bad, tot)
+    # generator parameters untouched by the discriminator step, moving averages advanced
+    for nme in tr.opt_g.names:
+        assert np.array_equal(tr.sess.params[nme].detach().cpu().numpy(), before[nme])
+    mm = "generator/g_cA1/moving_mean"
+    want_mm = 0.999 * before[mm] + 0.001 * stats["generator/g_cA1"][0].numpy()
+    assert rel(tr.sess.params[mm].detach().cpu().numpy(), want_mm) < 1e-5
+    # a generator step moves the generator only and lowers the L1 term on the same batch over a few steps
+    d_before = {n: tr.sess.params[n].detach().cpu().numpy().copy() for n in tr.opt_d.names}
+    l1 = [float(tr.gen_step(xs, ys)["gen_l1_loss"].detach()) for _ in range(6)]
+    for nme in tr.opt_d.names:
+        assert np.array_equal(tr.sess.params[nme].detach().cpu().numpy(), d_before[nme])
+    assert l1[-1] < l1[0]
+    assert np.isfinite(float(Ld["disc_loss"].detach()))
