@@ -92,7 +92,7 @@ typedef struct mpg_conv_seg {
     int32_t kh, kw;      /* kernel size, 1..7 */
     int32_t up_log2;     /* fused nearest upsample: src = (y >> up_log2, x >> up_log2) */
     int32_t w_exp;       /* F16F8 only: the exponent the weights were packed with */
-    int32_t pad_;
+    int32_t pad_hi;           /* 0: TF SAME, pad_before = (k-1)/2; 1: pad_before = k/2 (the data gradient of an even filter) */
 } mpg_conv_seg;
 
 typedef struct mpg_conv_desc {
@@ -197,11 +197,16 @@ int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, floa
 int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* dy,
                      int cout, int kh, int kw, int stride_h, int stride_w, float wscale, float* dw);
 /* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
- * convs, multipassGAN-4x.py:607-614).  Stride-1 odd filters can instead run mpg_conv2d_fused on dy
- * with the flipped, transposed filter. */
+ * convs, multipassGAN-4x.py:607-614).  The filter is passed with its channel axes swapped,
+ * w_hwoi[kh,kw,cout,cin].  Stride-1 filters can instead run mpg_conv2d_fused on dy with the
+ * flipped w_hwoi and pad_hi = 1. */
 int mpg_conv2d_dgrad(mpg_stream_t stream, const float* dy, int n, int h, int w, int cin,
-                     const float* w_hwio, int cout, int kh, int kw, int stride_h, int stride_w,
+                     const float* w_hwoi, int cout, int kh, int kw, int stride_h, int stride_w,
                      float wscale, float* dx);
+/* GAN.fully_connected_layer (GAN.py:438-456): y[rows,cout] = act(x[rows,k] @ (w[k,cout] * wscale) + bias).
+ * Its gradients are mpg_conv2d_wgrad / mpg_conv2d_dgrad with h = w = 1. */
+int mpg_fc_forward(mpg_stream_t stream, const float* x, int rows, int k, const float* w, int cout,
+                   float wscale, const float* bias, int act, float leak, float* y);
 /* out[c] = sum over pixels of x[p, c]  (bias gradient, GAN.py:683) */
 int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out);
 /* tf.contrib.layers.batch_norm(is_training=True) (GAN.py:110): batch mean / biased variance over

@@ -40,7 +40,7 @@ class ConvSeg(ctypes.Structure):
         ("kw", ctypes.c_int32),
         ("up_log2", ctypes.c_int32),
         ("w_exp", ctypes.c_int32),
-        ("pad_", ctypes.c_int32),
+        ("pad_hi", ctypes.c_int32),
     ]
 
 
@@ -98,6 +98,7 @@ PROTOTYPES = {
     # training step
     "mpg_conv2d_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mpg_fc_forward": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _F, _P]),
     "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),
     "mpg_bn_train_fwd": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P]),
     "mpg_bn_train_bwd": (_I, [_P, _P, _P, _Z, _I, _P, _P, _P, _F, _P, _P, _P]),

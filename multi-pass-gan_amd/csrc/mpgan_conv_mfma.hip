@@ -911,7 +911,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         o.kh = g.kh; o.kw = g.kw; o.up = g.up_log2;
         o.cgc = ss.cgc; o.nchunks = ss.nchunks; o.sc = ss.sc;
         o.ih = ps.th + g.kh - 1; o.iw = TW + g.kw - 1;
-        o.pt = (g.kh - 1) / 2; o.pl = (g.kw - 1) / 2;
+        o.pt = g.pad_hi ? g.kh / 2 : (g.kh - 1) / 2; o.pl = g.pad_hi ? g.kw / 2 : (g.kw - 1) / 2;
         o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2;
         o.np = ss.np; o.ni_img = ss.ni_img;
         o.sw_hi = o.sw_lo = 0;

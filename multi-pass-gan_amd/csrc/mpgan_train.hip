@@ -124,6 +124,8 @@ inline int micro(int c) { return c > 64 ? 8 : c > 32 ? 4 : c > 16 ? 2 : 1; }
 
 // ---------------------------------------------------------------- data gradient (any stride / filter)
 // dx[b,iy,ix,ci] = wscale * sum_{ky,kx,co} dy[b,oy,ox,co] * w[ky,kx,ci,co],  oy*sh + ky - pt == iy
+// wt is the filter with the channel axes swapped, [kh,kw,cout,cin]: the lanes of a wave (adjacent ci)
+// read adjacent weights while dy[co] is a broadcast
 __global__ void dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, float* __restrict__ dx,
                              ConvGeom g, float wscale) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
@@ -146,8 +148,8 @@ __global__ void dgrad_kernel(const float* __restrict__ dy, const float* __restri
             const int ox = nx / g.sw;
             if (ox >= g.ow) continue;
             const float* dp = dy + (((size_t)b * g.oh + oy) * g.ow + ox) * g.cout;
-            const float* wp = wt + ((size_t)(ky * g.kw + kx) * g.cin + ci) * g.cout;
-            for (int co = 0; co < g.cout; ++co) acc = fmaf(dp[co], wp[co], acc);
+            const float* wp = wt + (size_t)(ky * g.kw + kx) * g.cout * g.cin + ci;
+            for (int co = 0; co < g.cout; ++co) acc = fmaf(dp[co], wp[(size_t)co * g.cin], acc);
         }
     }
     dx[idx] = acc * wscale;
@@ -323,6 +325,42 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr,
     p[idx] -= lr_t * mm / (sqrtf(vv) + eps);
 }
 
+// fully connected layer: y[r][o] = act(wscale * sum_k x[r][k] * w[k][o] + b[o]); one block per (row, 64 outputs),
+// the K range is strided over the block and reduced through LDS
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, int k, int cout, float wscale,
+                                                     int act, float leak, float* __restrict__ y) {
+    __shared__ float red[BLK];
+    const int row = blockIdx.x;
+    const int o0 = blockIdx.y * 64;
+    const int no = min(64, cout - o0);
+    const int tid = threadIdx.x;
+    const float* xr = x + (size_t)row * k;
+    if (no == 1) {
+        float s = 0.f;
+        for (int i = tid; i < k; i += BLK) s = fmaf(xr[i], w[(size_t)i * cout + o0], s);
+        red[tid] = s;
+        __syncthreads();
+        for (int st = BLK / 2; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) y[(size_t)row * cout + o0] = mpg::apply_act(red[0] * wscale + (bias ? bias[o0] : 0.f), act, leak);
+        return;
+    }
+    // 4 k-lanes x 64 outputs
+    const int o = tid % 64, kl = tid / 64;
+    float s = 0.f;
+    if (o < no)
+        for (int i = kl; i < k; i += 4) s = fmaf(xr[i], w[(size_t)i * cout + o0 + o], s);
+    red[tid] = s;
+    __syncthreads();
+    if (kl == 0 && o < no) {
+        s = red[o] + red[64 + o] + red[128 + o] + red[192 + o];
+        y[(size_t)row * cout + o0 + o] = mpg::apply_act(s * wscale + (bias ? bias[o0 + o] : 0.f), act, leak);
+    }
+}
+
 int fill_geom(ConvGeom& g, int n, int h, int w, int cin, int cout, int kh, int kw, int sh, int sw) {
     g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw;
     g.oh = (h + sh - 1) / sh;
@@ -361,16 +399,26 @@ extern "C" int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int 
 }
 
 extern "C" int mpg_conv2d_dgrad(mpg_stream_t stream, const float* dy, int n, int h, int w, int cin,
-                                const float* w_hwio, int cout, int kh, int kw, int stride_h, int stride_w,
+                                const float* w_hwoi, int cout, int kh, int kw, int stride_h, int stride_w,
                                 float wscale, float* dx) {
-    MPG_REQUIRE(dy && w_hwio && dx, "mpg_conv2d_dgrad: null pointer");
+    MPG_REQUIRE(dy && w_hwoi && dx, "mpg_conv2d_dgrad: null pointer");
     MPG_GEOM_CHECK("mpg_conv2d_dgrad");
     ConvGeom g;
     fill_geom(g, n, h, w, cin, cout, kh, kw, stride_h, stride_w);
     const size_t total = (size_t)n * h * w * cin;
-    hipLaunchKernelGGL(dgrad_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, w_hwio, dx, g,
+    hipLaunchKernelGGL(dgrad_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, w_hwoi, dx, g,
                        wscale);
     MPG_LAUNCH_CHECK("dgrad_kernel");
+}
+
+extern "C" int mpg_fc_forward(mpg_stream_t stream, const float* x, int rows, int k, const float* w, int cout,
+                              float wscale, const float* bias, int act, float leak, float* y) {
+    MPG_REQUIRE(x && w && y, "mpg_fc_forward: null pointer");
+    MPG_REQUIRE(rows >= 1 && k >= 1 && cout >= 1, "mpg_fc_forward: bad shape");
+    MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_fc_forward: bad activation %d", act);
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(rows, (cout + 63) / 64), dim3(BLK), 0, (hipStream_t)stream, x, w, bias, k,
+                       cout, wscale, act, leak, y);
+    MPG_LAUNCH_CHECK("fc_fwd_kernel");
 }
 
 extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out) {

@@ -125,9 +125,10 @@ class Segment(object):
     """One K-slice of a fused convolution: G8 source (an fp32 NHWC tensor is converted on the
     fly), first channel group consumed, packed weights, fused nearest upsample."""
 
-    __slots__ = ("x", "packed", "g_off", "up_log2")
+    __slots__ = ("x", "packed", "g_off", "up_log2", "pad_hi")
 
-    def __init__(self, x, packed, c_off=0, up_log2=0):
+    def __init__(self, x, packed, c_off=0, up_log2=0, pad_hi=0):
+        self.pad_hi = int(pad_hi)
         if isinstance(x, torch.Tensor):
             x = to_g8(x, c_off, packed.cin, flavour_for(packed.prec))
             c_off = 0
@@ -167,6 +168,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         g.x, g.wpack = g8.buf.data_ptr(), pk.buf.data_ptr()
         g.cin, g.cgroups, g.g_off = pk.cin, g8.groups, s.g_off
         g.kh, g.kw, g.up_log2, g.w_exp = pk.kh, pk.kw, s.up_log2, pk.w_exp
+        g.pad_hi = s.pad_hi
     if bias is not None:
         b = _dev(bias, "bias")
         if b.numel() != p0.cout:

@@ -560,6 +560,9 @@ class Session(object):
             b = eff.float().contiguous()
             w = self.vars.get(wv.attrs["var"])
             xin = self._f32(env, x)
+            if is_fc and scale is None:
+                from . import train_ops
+                return train_ops.fc_forward(xin.contiguous(), w, conv.attrs["wscale"], b, act, leak)
             if is_fc:
                 y = ops.conv2d_direct(xin.reshape(xin.shape[0], 1, 1, xin.shape[1]).contiguous(),
                                       w.reshape(1, 1, w.shape[0], w.shape[1]), (1, 1), conv.attrs["wscale"], scale, b,

@@ -19,12 +19,26 @@ from . import graph as G
 TRAINABLE_KINDS = ("weight", "bias", "gamma", "beta")
 
 
-def _mfma_fwd_ok(kh, kw, cout, stride):
-    return stride == (1, 1) and kh <= 7 and kw <= 7 and cout <= 128
+def _mfma_ok(kh, kw, width, stride):
+    """the fused MFMA kernel takes stride-1 filters up to 7x7 and 128 output channels per launch;
+    wider layers (the 256-wide d_c4, multipassGAN-4x.py:614) run as two launches"""
+    return stride == (1, 1) and kh <= 7 and kw <= 7 and width <= 512
 
 
-def _mfma_dgrad_ok(kh, kw, cin, stride):
-    return stride == (1, 1) and kh % 2 == 1 and kw % 2 == 1 and kh <= 7 and kw <= 7 and cin <= 128
+def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0):
+    """conv2d_SAME(x, w * wscale) [+ bias, act] on the MFMA kernel, output channels in chunks of 128"""
+    cout = w.shape[3]
+    outs = []
+    for c0 in range(0, cout, 128):
+        c1 = min(cout, c0 + 128)
+        wc = w if (c0 == 0 and c1 == cout) else w[..., c0:c1].contiguous()
+        pk = ops.pack_conv_weights(wc, wscale=wscale, prec=prec)
+        bc = None if bias is None else (bias if (c0 == 0 and c1 == cout) else bias[c0:c1].contiguous())
+        seg = ops.Segment(x, pk, pad_hi=pad_hi)
+        if len(outs) == 0 and c1 < cout and isinstance(x, torch.Tensor):
+            x = seg.x                       # reuse the G8 conversion for the other chunks
+        outs.append(ops.conv2d_fused([seg], (seg.x.h, seg.x.w), bias=bc, act=act, leak=leak))
+    return outs[0] if len(outs) == 1 else torch.cat(outs, dim=3)
 
 
 class ConvLayerFn(torch.autograd.Function):
@@ -38,9 +52,12 @@ class ConvLayerFn(torch.autograd.Function):
         x = x.contiguous()
         bn = gamma is not None
         conv_act = None if bn else act
-        if _mfma_fwd_ok(kh, kw, cout, stride):
-            pk = ops.pack_conv_weights(w.detach().contiguous(), wscale=wscale, prec=cfg["prec"])
-            lin = ops.conv2d_fused([ops.Segment(x, pk)], (x.shape[1], x.shape[2]), bias=b, act=conv_act, leak=leak)
+        if cfg.get("fc"):
+            lin = train_ops.fc_forward(x.reshape(x.shape[0], cin), w.detach().reshape(cin, cout), wscale, b, conv_act,
+                                       leak).reshape(x.shape[0], 1, 1, cout)
+        elif _mfma_ok(kh, kw, cout, stride):
+            lin = _mfma_conv(x, w.detach().contiguous(), wscale, cfg["prec"], b.detach() if b is not None else None,
+                             conv_act, leak)
         else:
             lin = ops.conv2d_direct(x, w.detach().contiguous(), stride, wscale, None, b, conv_act, leak)
         if bn:
@@ -72,10 +89,9 @@ class ConvLayerFn(torch.autograd.Function):
         dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale) if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
-            if _mfma_dgrad_ok(kh, kw, cin, stride):
+            if _mfma_ok(kh, kw, cin, stride) and not cfg.get("fc"):
                 wt = w.detach().flip(0, 1).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin], taps mirrored
-                pk = ops.pack_conv_weights(wt, wscale=wscale, prec=cfg["prec"])
-                dx = ops.conv2d_fused([ops.Segment(d, pk)], (x.shape[1], x.shape[2]))
+                dx = _mfma_conv(d, wt, wscale, cfg["prec"], pad_hi=1)
             else:
                 dx = train_ops.conv2d_dgrad(d, w.detach(), (x.shape[1], x.shape[2]), stride, wscale)
         return dx, dw, db, dgamma, dbeta, None
@@ -305,7 +321,7 @@ class TrainSession(object):
             stride = (1, 1)
         else:
             w4, stride = w, tuple(conv.attrs["stride"])
-        cfg = {"stride": stride, "wscale": conv.attrs["wscale"], "act": act, "leak": leak, "prec": self.prec,
+        cfg = {"stride": stride, "wscale": conv.attrs["wscale"], "act": act, "leak": leak, "prec": self.prec, "fc": is_fc,
                "eps": bn.attrs["eps"] if bn is not None else 0.0}
         gamma = beta = None
         if bn is not None:

@@ -28,8 +28,8 @@ def conv2d_wgrad(x, dy, kh, kw, stride=(1, 1), wscale=1.0):
 def conv2d_dgrad(dy, w_hwio, in_hw, stride=(1, 1), wscale=1.0):
     """dL/dx of y = conv2d_SAME(x, W * wscale) for x of spatial size in_hw."""
     lib = _lib.load()
-    dy, w = _cont(dy, "dy"), _cont(w_hwio, "w_hwio")
-    kh, kw, cin, cout = w.shape
+    kh, kw, cin, cout = w_hwio.shape
+    dy, w = _cont(dy, "dy"), _cont(w_hwio.permute(0, 1, 3, 2), "w_hwoi")
     n = dy.shape[0]
     h, wd = in_hw
     sh, sw = stride
@@ -39,6 +39,21 @@ def conv2d_dgrad(dy, w_hwio, in_hw, stride=(1, 1), wscale=1.0):
     _lib.check(lib.mpg_conv2d_dgrad(_stream(), _ptr(dy), n, h, wd, cin, _ptr(w), cout, kh, kw, sh, sw, float(wscale),
                                     _ptr(dx)), "mpg_conv2d_dgrad")
     return dx
+
+
+def fc_forward(x, w, wscale=1.0, bias=None, act=None, leak=0.2):
+    """GAN.fully_connected_layer (GAN.py:438-456): act(x @ (w * wscale) + bias), x [rows, k], w [k, cout]"""
+    lib = _lib.load()
+    x, w = _cont(x, "x"), _cont(w, "w")
+    rows, k = x.shape
+    if w.shape[0] != k:
+        raise _lib.MpgError("fc_forward: x has %d columns, w %d rows" % (k, w.shape[0]))
+    cout = w.shape[1]
+    y = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    b = _cont(bias, "bias") if bias is not None else None
+    _lib.check(lib.mpg_fc_forward(_stream(), _ptr(x), rows, k, _ptr(w), cout, float(wscale), _ptr(b), _lib.act_id(act),
+                                  leak, _ptr(y)), "mpg_fc_forward")
+    return y
 
 
 def channel_sum(x):
