@@ -196,6 +196,14 @@ int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, floa
  * wscale * sum_p x[p + tap] * dy[p].  dy is [n, ceil(h/sh), ceil(w/sw), cout]; dw is overwritten. */
 int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* dy,
                      int cout, int kh, int kw, int stride_h, int stride_w, float wscale, float* dw);
+/* The same weight gradient on the matrix cores for stride-1 filters (kh <= 7, kw in 1,3,4,5):
+ * x and dy are rewritten channel-major in fp16 (hi + lo planes, power-of-two scaled) inside
+ * `workspace` (>= mpg_conv2d_wgrad_mfma_ws_bytes, 256-byte aligned), then contracted over pixels
+ * with v_mfma_f32_32x32x16_f16.  prec MPG_PREC_F16X3 (three products, fp32-grade) or MPG_PREC_F16X1. */
+size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout);
+int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
+                          const float* dy, int cout, int kh, int kw, float wscale, int prec,
+                          void* workspace, size_t workspace_bytes, float* dw);
 /* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
  * convs, multipassGAN-4x.py:607-614).  The filter is passed with its channel axes swapped,
  * w_hwoi[kh,kw,cout,cin].  Stride-1 filters can instead run mpg_conv2d_fused on dy with the

@@ -1,0 +1,379 @@
+// Weight gradient of the stride-1 SAME convolution on the matrix cores (gfx950).
+//
+//   dW[ky][kx][ci][co] = wscale * sum_{b,oy,ox} x[b, oy+ky-pt, ox+kx-pl, ci] * dy[b, oy, ox, co]
+//
+// is, per filter tap, a GEMM whose contraction runs over PIXELS.  v_mfma_f32_32x32x16_f16 wants the
+// 8 contraction elements of a lane contiguous, so both operands are first rewritten channel-major
+// ("P16": [N][H][C][2 planes hi,lo][Wp] fp16, Wp = W rounded up to 8, scaled by a power of two taken
+// from the tensor's absolute maximum so that small gradients stay in the fp16 normal range).  Then
+//   * a block (4 waves, one per SIMD, so each wave may hold up to 512 registers) owns one filter row ky,
+//     up to 128 input x 128 output channels, and a range of output rows; it walks the rows in chunks
+//     of 32*KS pixels, staging the x piece (with an 8-pixel halo on both sides) and the dy piece in
+//     LDS, double buffered through registers;
+//   * a wave owns a 32-channel ci tile, COTW co tiles and all KW taps of the row: KW*COTW accumulator
+//     tiles (20 for a 5x5 128->128 layer).  Per 16-pixel k-step it reads one 24-pixel window of x per plane (3 x ds_read_b128) and
+//     derives the KW shifted A fragments in registers (v_alignbit for odd shifts), so x is read from
+//     LDS once for all taps; dy fragments are single aligned ds_read_b128;
+//   * precision 3 adds the hi*lo and lo*hi products (fp32-grade, like MPG_PREC_F16X3); precision 1
+//     keeps hi*hi only;
+//   * partial sums of the pixel ranges are combined with fp32 atomics into dW.
+#include "mpgan_internal.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BLK = 256;
+
+__device__ __forceinline__ float pow2_scale(float amax) {
+    // amax = m * 2^e, m in [0.5,1)  ->  scaled maximum in [2^8, 2^9)
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(amax, &e);
+    return ldexpf(1.f, 9 - e);
+}
+
+__global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned int* __restrict__ out) {
+    __shared__ float red[BLK];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) m = fmaxf(m, fabsf(x[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = BLK / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0]));   // non-negative floats order like their bit patterns
+}
+
+// fp32 NHWC -> P16.  block: one image row, 64 pixels, 64 channels through an LDS transpose.
+__global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x, int h, int w, int c, int wp,
+                                                     const float* __restrict__ amax, _Float16* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int row = blockIdx.x;            // b*h + y
+    const int x0 = blockIdx.y * 64;
+    const int c0 = blockIdx.z * 64;
+    const float scale = pow2_scale(*amax);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 64 * 64; e += 256) {
+        const int px = e / 64, ch = e % 64;
+        float v = 0.f;
+        if (x0 + px < w && c0 + ch < c) v = x[((size_t)row * w + x0 + px) * c + c0 + ch];
+        tile[px][ch] = v * scale;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 8; e += 256) {
+        const int u = e % 8, ch = e / 8;
+        if (c0 + ch >= c || x0 + 8 * u >= wp) continue;
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = tile[8 * u + i][ch];
+            const _Float16 hh = (_Float16)v;
+            hi[i] = hh;
+            lo[i] = (_Float16)(v - (float)hh);
+        }
+        _Float16* o = out + (((size_t)row * c + c0 + ch) * 2) * wp + x0 + 8 * u;
+        *reinterpret_cast<half8*>(o) = hi;
+        *reinterpret_cast<half8*>(o + wp) = lo;
+    }
+}
+
+struct WgArgs {
+    const _Float16* xp;      // P16 of x  [N][H][cin_total][2][wp]
+    const _Float16* dp;      // P16 of dy [N][H][cout_total][2][wp]
+    const float* amax;       // [0] x, [1] dy
+    float* dw;               // [kh][kw][cin_total][cout_total]
+    int n, h, w, wp;
+    int cin_total, cout_total, ci0, co0, cin, cout;   // channel window of this launch (cin, cout <= 128)
+    int kh, pt, pl;
+    int cit, cog, ks;        // waves = cit * cog * ks = 4
+    int chunk;               // pixels per chunk = 32 * ks
+    int xrowb, drowb;        // LDS row strides in bytes
+    int nsplit, rows_per_split;
+    float wscale;
+};
+
+template <int KW, int COTW, int PREC>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    // XCD-aware order: the kh blocks of one row range land on the same XCD (shared L2)
+    const int xcd = blockIdx.x % 8, jj = blockIdx.x / 8;
+    const int ky = jj % a.kh;
+    const int split = (jj / a.kh) * 8 + xcd;
+    if (split >= a.nsplit) return;
+    const int cit = wave % a.cit;
+    const int cog = (wave / a.cit) % a.cog;
+    const int ks = wave / (a.cit * a.cog);
+
+    const int nplane = PREC == 3 ? 2 : 1;
+    const int xch = a.cit * 32, dch = a.cog * COTW * 32;
+    const int xbytes = xch * nplane * a.xrowb, dbytes = dch * nplane * a.drowb;
+    char* xs[2] = {lds, lds + xbytes + dbytes};
+    char* dsm[2] = {lds + xbytes, lds + 2 * xbytes + dbytes};
+
+    // global -> LDS copy plan: 16-byte units; unit -> (row = channel*nplane + plane, offset)
+    const int xupr = (a.chunk + 16) / 8, dupr = a.chunk / 8;          // units per row
+    const int xunits = xch * nplane * xupr, dunits = dch * nplane * dupr;
+    constexpr int XU = 6, DU = 4;                                      // units per thread
+    u32x4 xreg[XU], dreg[DU];
+
+    const int total_rows = a.n * a.h;
+    const int row_begin = split * a.rows_per_split;
+    const int row_end = min(total_rows, row_begin + a.rows_per_split);
+    const int chunks_per_row = (a.w + a.chunk - 1) / a.chunk;
+    const int nwork = (row_end - row_begin) * chunks_per_row;
+
+    f32x16 acc[KW][COTW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int t = 0; t < COTW; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[k][t][v] = 0.f;
+
+    auto fetch = [&](int wi) {
+        const int row = row_begin + wi / chunks_per_row;        // output row b*h + oy
+        const int x0 = (wi % chunks_per_row) * a.chunk;
+        const int oy = row % a.h;
+        const int iy = oy + ky - a.pt;
+        const bool row_ok = iy >= 0 && iy < a.h;
+        const size_t xrow = (size_t)(row - oy + iy) * a.cin_total;
+        const size_t drow = (size_t)row * a.cout_total;
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = tid + i * 256;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (u < xunits && row_ok) {
+                const int rr = u / xupr, off = u % xupr;
+                const int ch = rr / nplane, pln = rr % nplane;
+                const int px = x0 - 8 + off * 8;
+                if (ch < a.cin && px >= 0 && px < a.wp)
+                    v = *reinterpret_cast<const u32x4*>(a.xp + ((xrow + a.ci0 + ch) * 2 + pln) * a.wp + px);
+            }
+            xreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < DU; ++i) {
+            const int u = tid + i * 256;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (u < dunits && row_ok) {
+                const int rr = u / dupr, off = u % dupr;
+                const int ch = rr / nplane, pln = rr % nplane;
+                const int px = x0 + off * 8;
+                if (ch < a.cout && px < a.wp)
+                    v = *reinterpret_cast<const u32x4*>(a.dp + ((drow + a.co0 + ch) * 2 + pln) * a.wp + px);
+            }
+            dreg[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XU; ++i) {
+            const int u = tid + i * 256;
+            if (u < xunits) {
+                const int rr = u / xupr, off = u % xupr;
+                const int ch = rr / nplane, pln = rr % nplane;
+                *reinterpret_cast<u32x4*>(xs[buf] + (pln * xch + ch) * a.xrowb + off * 16) = xreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DU; ++i) {
+            const int u = tid + i * 256;
+            if (u < dunits) {
+                const int rr = u / dupr, off = u % dupr;
+                const int ch = rr / nplane, pln = rr % nplane;
+                *reinterpret_cast<u32x4*>(dsm[buf] + (pln * dch + ch) * a.drowb + off * 16) = dreg[i];
+            }
+        }
+    };
+
+    if (nwork > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    const int ksteps = a.chunk / 16;
+    for (int wi = 0; wi < nwork; ++wi) {
+        const int buf = wi & 1;
+        if (wi + 1 < nwork) fetch(wi + 1);
+        const char* xb = xs[buf] + (cit * 32 + r) * a.xrowb + hh * 16;
+        const char* db = dsm[buf] + ((cog * COTW) * 32 + r) * a.drowb + hh * 16;
+        for (int j = ks; j < ksteps && ks < a.ks; j += a.ks) {
+            // 24-pixel window of x per plane: pixels [16j + 8h - 8, 16j + 8h + 16) relative to the chunk start
+            unsigned int win[2][12];
+#pragma unroll
+            for (int pln = 0; pln < nplane; ++pln) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pln * xch * a.xrowb + j * 32 + q * 16);
+                    win[pln][4 * q + 0] = v[0]; win[pln][4 * q + 1] = v[1];
+                    win[pln][4 * q + 2] = v[2]; win[pln][4 * q + 3] = v[3];
+                }
+            }
+            half8 bfr[2][COTW];
+#pragma unroll
+            for (int pln = 0; pln < nplane; ++pln)
+#pragma unroll
+                for (int t = 0; t < COTW; ++t)
+                    bfr[pln][t] = *reinterpret_cast<const half8*>(db + pln * dch * a.drowb + t * 32 * a.drowb + j * 32);
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                // pixels [8 + s, 16 + s) of the window, s = kx - pl (|s| <= 3)
+                const int s = kx - (KW - 1) / 2;
+                half8 afr[2];
+#pragma unroll
+                for (int pln = 0; pln < nplane; ++pln) {
+                    u32x4 f;
+                    if ((s & 1) == 0) {
+                        const int q = (8 + s) / 2;
+                        f[0] = win[pln][q]; f[1] = win[pln][q + 1]; f[2] = win[pln][q + 2]; f[3] = win[pln][q + 3];
+                    } else {
+                        const int q = (7 + s) / 2;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            f[i] = __builtin_amdgcn_alignbit(win[pln][q + i + 1], win[pln][q + i], 16);
+                    }
+                    afr[pln] = __builtin_bit_cast(half8, f);
+                }
+#pragma unroll
+                for (int t = 0; t < COTW; ++t) {
+                    acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfr[0][t], acc[kx][t], 0, 0, 0);
+                    if (PREC == 3) {
+                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfr[1][t], acc[kx][t], 0, 0, 0);
+                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[1], bfr[0][t], acc[kx][t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (wi + 1 < nwork) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D row = (v&3) + 8*(v>>2) + 4*(lane>>5) is the input channel, column lane&31 the output channel
+    const float unscale = a.wscale / (pow2_scale(a.amax[0]) * pow2_scale(a.amax[1]));
+#pragma unroll
+    for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+        for (int t = 0; t < COTW; ++t) {
+            const int co = (cog * COTW + t) * 32 + r;
+            if (co >= a.cout) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ci = cit * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+                const float val = acc[kx][t][v];
+                if (ci < a.cin && val != 0.f)
+                    atomicAdd(a.dw + ((size_t)(ky * KW + kx) * a.cin_total + a.ci0 + ci) * a.cout_total + a.co0 + co,
+                              val * unscale);
+            }
+        }
+}
+
+template <int KW, int COTW, int PREC>
+hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes) {
+    auto kern = wgrad_mfma_kernel<KW, COTW, PREC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, a);
+    return hipGetLastError();
+}
+
+inline size_t p16_elems(int n, int h, int w, int c) { return (size_t)n * h * c * 2 * ((w + 7) & ~7); }
+
+}  // namespace
+
+extern "C" size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout) {
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return 0;
+    return 256 + (p16_elems(n, h, w, cin) + p16_elems(n, h, w, cout)) * sizeof(_Float16);
+}
+
+extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
+                                     const float* dy, int cout, int kh, int kw, float wscale, int prec,
+                                     void* workspace, size_t workspace_bytes, float* dw) {
+    MPG_REQUIRE(x && dy && dw && workspace, "mpg_conv2d_wgrad_mfma: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_wgrad_mfma: bad shape");
+    MPG_REQUIRE(kh >= 1 && kh <= 7 && (kw == 1 || kw == 3 || kw == 4 || kw == 5),
+                "mpg_conv2d_wgrad_mfma: filter %dx%d not built", kh, kw);
+    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3, "mpg_conv2d_wgrad_mfma: prec %d", prec);
+    MPG_REQUIRE(workspace_bytes >= mpg_conv2d_wgrad_mfma_ws_bytes(n, h, w, cin, cout) &&
+                    (((uintptr_t)workspace) & 255) == 0,
+                "mpg_conv2d_wgrad_mfma: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int wp = (w + 7) & ~7;
+    float* amax = (float*)workspace;
+    _Float16* xp = (_Float16*)((char*)workspace + 256);
+    _Float16* dp = xp + p16_elems(n, h, w, cin);
+    hipError_t e = hipMemsetAsync(amax, 0, 256, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dw, 0, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
+    const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nx + BLK * 8 - 1) / (BLK * 8) > 1024 ? 1024 : (nx + BLK * 8 - 1) / (BLK * 8))),
+                       dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nd + BLK * 8 - 1) / (BLK * 8) > 1024 ? 1024 : (nd + BLK * 8 - 1) / (BLK * 8))),
+                       dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
+    hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cin + 63) / 64), dim3(256), 0, s, x, h, w, cin, wp,
+                       amax, xp);
+    hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cout + 63) / 64), dim3(256), 0, s, dy, h, w, cout, wp,
+                       amax + 1, dp);
+
+    // a wave keeps KW * COTW accumulator tiles of 16 registers in the 256 AccVGPRs: 16 tiles at most, so a
+    // 5-wide filter row takes 64 output channels per launch (x is then staged twice, from L2)
+    const int co_step = kw >= 5 ? 64 : 128;
+    for (int ci0 = 0; ci0 < cin; ci0 += 128)
+        for (int co0 = 0; co0 < cout; co0 += co_step) {
+            WgArgs a;
+            a.xp = xp; a.dp = dp; a.amax = amax; a.dw = dw;
+            a.n = n; a.h = h; a.w = w; a.wp = wp;
+            a.cin_total = cin; a.cout_total = cout; a.ci0 = ci0; a.co0 = co0;
+            a.cin = cin - ci0 < 128 ? cin - ci0 : 128;
+            a.cout = cout - co0 < co_step ? cout - co0 : co_step;
+            a.kh = kh; a.pt = (kh - 1) / 2; a.pl = (kw - 1) / 2;
+            a.wscale = wscale;
+            const int nci = (a.cin + 31) / 32, nco = (a.cout + 31) / 32;
+            a.cit = nci > 2 ? 4 : nci;                           // 1, 2, 4 ci tiles, one per wave
+            const int avail = 4 / a.cit;                          // waves left for output-channel groups
+            int cog = nco >= 3 ? 4 : nco;                         // 1, 2, 4
+            if (cog > avail) cog = avail;
+            a.cog = cog;
+            int cotw = (nco + cog - 1) / cog;                     // co tiles per wave: 1, 2, 4
+            if (cotw == 3) cotw = 4;
+            const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
+            a.ks = 4 / (a.cit * a.cog);                           // waves left over split the 16-pixel k-steps of a chunk
+            a.chunk = 32 * a.ks;
+            // short rows, and at most 6 / 4 16-byte units per thread in the copy plan
+            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8) > 6 * 256 ||
+                                    a.cog * cotw * 32 * npl * (a.chunk / 8) > 4 * 256))
+                a.chunk /= 2;
+            if (a.chunk / 16 < a.ks) a.ks = a.chunk / 16;         // the other waves idle (tiny layers)
+            a.xrowb = (a.chunk + 16) * 2 + 16;
+            a.drowb = a.chunk * 2 + 16;
+            const size_t lds = 2 * ((size_t)a.cit * 32 * npl * a.xrowb + (size_t)a.cog * cotw * 32 * npl * a.drowb);
+            MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_wgrad_mfma: LDS plan %zu bytes", lds);
+            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8) <= 6 * 256 && a.cog * cotw * 32 * npl * (a.chunk / 8) <= 4 * 256,
+                        "mpg_conv2d_wgrad_mfma: copy plan");
+            const int rows = n * h;
+            int want = 1024 / kh;
+            if (want < 1) want = 1;
+            int nsplit = want < rows ? want : rows;
+            a.rows_per_split = (rows + nsplit - 1) / nsplit;
+            a.nsplit = (rows + a.rows_per_split - 1) / a.rows_per_split;
+            const int blocks = ((a.nsplit + 7) / 8) * 8 * kh;
+            hipError_t le = hipErrorInvalidValue;
+#define MPG_WGM(K, C)                                                                        \
+    if (kw == K && cotw == C)                                                                \
+        le = prec == MPG_PREC_F16X3 ? launch<K, C, 3>(s, a, blocks, lds) : launch<K, C, 1>(s, a, blocks, lds)
+            MPG_WGM(1, 1); MPG_WGM(1, 2); MPG_WGM(1, 4); MPG_WGM(3, 1); MPG_WGM(3, 2); MPG_WGM(3, 4);
+            MPG_WGM(4, 1); MPG_WGM(4, 2); MPG_WGM(4, 4); MPG_WGM(5, 1); MPG_WGM(5, 2);
+#undef MPG_WGM
+            if (le != hipSuccess) return mpg::hip_check(le, "wgrad_mfma_kernel");
+        }
+    MPG_LAUNCH_CHECK("mpg_conv2d_wgrad_mfma");
+}

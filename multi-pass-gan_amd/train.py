@@ -86,7 +86,12 @@ class ConvLayerFn(torch.autograd.Function):
         if ctx.bn:
             d, dgamma, dbeta = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"])
         db = train_ops.channel_sum(d) if ctx.has_bias else None
-        dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            if train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and cfg.get("wgrad_mfma", True):
+                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"])
+            else:
+                dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale)
         dx = None
         if ctx.needs_input_grad[0]:
             if _mfma_ok(kh, kw, cin, stride) and not cfg.get("fc"):

@@ -25,6 +25,26 @@ def conv2d_wgrad(x, dy, kh, kw, stride=(1, 1), wscale=1.0):
     return dw
 
 
+def wgrad_mfma_ok(kh, kw, stride):
+    return tuple(stride) == (1, 1) and 1 <= kh <= 7 and kw in (1, 3, 4, 5)
+
+
+def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3):
+    """stride-1 weight gradient on the matrix cores (mpg_conv2d_wgrad_mfma)"""
+    lib = _lib.load()
+    x, dy = _cont(x, "x"), _cont(dy, "dy")
+    n, h, w, cin = x.shape
+    cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (n, h, w):
+        raise _lib.MpgError("conv2d_wgrad_mfma: dy shape %s does not match x %s" % (tuple(dy.shape), tuple(x.shape)))
+    nbytes = lib.mpg_conv2d_wgrad_mfma_ws_bytes(n, h, w, cin, cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    dw = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_conv2d_wgrad_mfma(_stream(), _ptr(x), n, h, w, cin, _ptr(dy), cout, kh, kw, float(wscale), prec,
+                                         _ptr(ws), nbytes, _ptr(dw)), "mpg_conv2d_wgrad_mfma")
+    return dw
+
+
 def conv2d_dgrad(dy, w_hwio, in_hw, stride=(1, 1), wscale=1.0):
     """dL/dx of y = conv2d_SAME(x, W * wscale) for x of spatial size in_hw."""
     lib = _lib.load()

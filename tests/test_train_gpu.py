@@ -74,6 +74,44 @@ def test_conv_wgrad_dgrad(case):
     assert rel(dx, dx_ref) < 1e-5
 
 
+WG_MFMA_CASES = [
+    # n, h, w, cin, cout, k
+    (2, 16, 16, 4, 8, 5), (2, 16, 16, 32, 128, 5), (1, 24, 20, 128, 128, 3), (3, 8, 8, 128, 32, 5),
+    (2, 16, 16, 8, 1, 5), (2, 16, 16, 1, 2, 5), (2, 12, 12, 9, 17, 1), (2, 8, 8, 128, 256, 4),
+    (1, 32, 64, 128, 128, 5), (2, 16, 40, 64, 96, 5), (1, 8, 300, 33, 65, 3), (2, 64, 64, 8, 32, 5),
+    (2, 16, 16, 200, 40, 1), (1, 16, 16, 40, 72, 4),
+]
+
+
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("case", WG_MFMA_CASES)
+def test_conv_wgrad_mfma(case, prec):
+    """matrix-core weight gradient vs float64 autograd: 3-product mode fp32-grade, 1-product fp16-grade"""
+    from mpgan_amd import train_ops
+    n, h, w, cin, cout, k = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    dy = (rng.standard_normal((n, h, w, cout)) * 1e-6).astype(np.float32)      # small gradients: exercises the scaling
+    wscale = float(np.float32(math.sqrt(2.0) / math.sqrt(k * k * cin)))
+    _, dw_ref = ref_conv_grads(x, wt, dy, 1, wscale)
+    dw = train_ops.conv2d_wgrad_mfma(dev(x), dev(dy), k, k, wscale, prec).cpu().numpy()
+    assert dw.shape == dw_ref.shape
+    assert rel(dw, dw_ref) < (2e-6 if prec == 3 else 2e-3)
+
+
+def test_conv_wgrad_mfma_zero_and_constant():
+    from mpgan_amd import train_ops
+    x = np.ones((1, 8, 8, 3), np.float32)
+    dy = np.zeros((1, 8, 8, 5), np.float32)
+    assert np.array_equal(train_ops.conv2d_wgrad_mfma(dev(x), dev(dy), 3, 3).cpu().numpy(), np.zeros((3, 3, 3, 5), np.float32))
+    dy[:] = 1.0
+    dw = train_ops.conv2d_wgrad_mfma(dev(x), dev(dy), 3, 3).cpu().numpy()
+    # number of valid (pixel, shifted pixel) pairs per tap of an 8x8 image: (8 - |dy|)(8 - |dx|)
+    want = np.array([[(8 - abs(a)) * (8 - abs(b)) for b in (-1, 0, 1)] for a in (-1, 0, 1)], np.float32)
+    assert np.array_equal(dw, np.broadcast_to(want[:, :, None, None], dw.shape))
+
+
 @pytest.mark.parametrize("bn", [False, True])
 @pytest.mark.parametrize("case", [(2, 16, 16, 8, 32, 5, 1, "relu"), (2, 16, 16, 32, 8, 5, 1, None),
                                   (2, 16, 16, 16, 16, 1, 1, "lrelu"), (2, 16, 16, 2, 32, 4, 2, "lrelu"),
