@@ -218,11 +218,12 @@ int mpg_fc_forward(mpg_stream_t stream, const float* x, int rows, int k, const f
 /* out[c] = sum over pixels of x[p, c]  (bias gradient, GAN.py:683) */
 int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out);
 /* tf.contrib.layers.batch_norm(is_training=True) (GAN.py:110): batch mean / biased variance over
- * all pixels, y = act((x - mean) * rsqrt(var + eps) * gamma + beta); the moments are returned for
- * the moving-average update done by the caller. */
+ * all pixels, y = act((x - mean) * rsqrt(var + eps) * gamma + beta); the moments are returned, and
+ * the moving averages (the UPDATE_OPS, multipassGAN-4x.py:773-776) are advanced in place when
+ * moving_mean / moving_var are given: moving = decay * moving + (1 - decay) * batch. */
 int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
                      const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
-                     float* batch_var);
+                     float* batch_var, float* moving_mean, float* moving_var, float decay);
 /* gradient of the normalisation above (dy is taken before the activation) */
 int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
                      const float* batch_mean, const float* batch_var, const float* gamma, float eps,
@@ -241,9 +242,10 @@ int mpg_avg_pool2_bwd(mpg_stream_t stream, const float* dy, int n, int h, int w,
 int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, size_t n, float t, float* out);
 /* tf.train.AdamOptimizer update on a flat parameter buffer (multipassGAN-4x.py:880-902):
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t * m / (sqrt(v) + eps), with
- * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+ * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) computed by the caller and read from DEVICE memory (one float),
+ * so that a captured hipGraph of the iteration can be replayed with a new step size. */
 int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, size_t n,
-                  float lr_t, float beta1, float beta2, float eps);
+                  const float* lr_t, float beta1, float beta2, float eps);
 
 #ifdef __cplusplus
 }

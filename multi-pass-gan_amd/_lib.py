@@ -102,14 +102,14 @@ PROTOTYPES = {
     "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_fc_forward": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _F, _P]),
     "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),
-    "mpg_bn_train_fwd": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P]),
+    "mpg_bn_train_fwd": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _F]),
     "mpg_bn_train_bwd": (_I, [_P, _P, _P, _Z, _I, _P, _P, _P, _F, _P, _P, _P]),
     "mpg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     "mpg_pixel_norm_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     "mpg_resize_nearest_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
     "mpg_avg_pool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mpg_lerp": (_I, [_P, _P, _P, _Z, _F, _P]),
-    "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _F, _F, _F, _F]),
+    "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _P, _F, _F, _F]),
 }
 
 _lib = None

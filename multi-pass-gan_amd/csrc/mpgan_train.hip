@@ -210,9 +210,17 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
                        aux0, aux1, inv_n, eps, out0, out1, ppb);
 }
 
-__global__ void scale_vec_kernel(float* v, int c, float s) {
+// sums -> batch mean / biased variance, and the moving averages of tf.contrib batch_norm
+// (moving = decay * moving + (1 - decay) * batch) when their pointers are given
+__global__ void bn_finalize_kernel(float* mean, float* var, int c, float inv_n, float* moving_mean,
+                                   float* moving_var, float decay) {
     const int i = blockIdx.x * BLK + threadIdx.x;
-    if (i < c) v[i] *= s;
+    if (i >= c) return;
+    const float m = mean[i] * inv_n, v = var[i] * inv_n;
+    mean[i] = m;
+    var[i] = v;
+    if (moving_mean) moving_mean[i] = decay * moving_mean[i] + (1.f - decay) * m;
+    if (moving_var) moving_var[i] = decay * moving_var[i] + (1.f - decay) * v;
 }
 
 // y = act((x - mean) * rsqrt(var + eps) * gamma + beta)
@@ -314,9 +322,11 @@ __global__ void lerp_kernel(const float* __restrict__ x, const float* __restrict
 
 // tf.train.AdamOptimizer: p -= lr_t * m / (sqrt(v) + eps), lr_t = lr * sqrt(1-b2^t) / (1-b1^t)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps) {
+                            float* __restrict__ v, size_t n, const float* __restrict__ lr_ptr, float b1, float b2,
+                            float eps) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
     if (idx >= n) return;
+    const float lr_t = *lr_ptr;
     const float g = gr[idx];
     const float mm = m[idx] + (g - m[idx]) * (1.f - b1);
     const float vv = v[idx] + (g * g - v[idx]) * (1.f - b2);
@@ -433,19 +443,24 @@ extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix,
 
 extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
                                 const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
-                                float* batch_var) {
+                                float* batch_var, float* moving_mean, float* moving_var, float decay) {
     MPG_REQUIRE(x && gamma && beta && y && batch_mean && batch_var, "mpg_bn_train_fwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_fwd: bad shape");
     MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_bn_train_fwd: bad activation %d", act);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(batch_mean, 0, (size_t)c * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)c * sizeof(float), s);
+    hipError_t e;
+    if (batch_var == batch_mean + c) {
+        e = hipMemsetAsync(batch_mean, 0, (size_t)2 * c * sizeof(float), s);
+    } else {
+        e = hipMemsetAsync(batch_mean, 0, (size_t)c * sizeof(float), s);
+        if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)c * sizeof(float), s);
+    }
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
     const float inv_n = 1.f / (float)npix;
     launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, nullptr);
     launch_chan_sum<1>(s, x, nullptr, npix, c, batch_mean, nullptr, inv_n, 0.f, batch_var, nullptr);
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, c, inv_n);
-    hipLaunchKernelGGL(scale_vec_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_var, c, inv_n);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
+                       moving_mean, moving_var, decay);
     const size_t total = npix * c;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
                        gamma, beta, eps, act, leak, y);
@@ -459,8 +474,13 @@ extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const floa
                 "mpg_bn_train_bwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), s);
-    if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), s);
+    hipError_t e;
+    if (dbeta == dgamma + c) {
+        e = hipMemsetAsync(dgamma, 0, (size_t)2 * c * sizeof(float), s);
+    } else {
+        e = hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), s);
+        if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), s);
+    }
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
     launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
     const size_t total = npix * c;
@@ -515,8 +535,8 @@ extern "C" int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, siz
 }
 
 extern "C" int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, size_t n,
-                             float lr_t, float beta1, float beta2, float eps) {
-    MPG_REQUIRE(p && grad && m && v, "mpg_adam_step: null pointer");
+                             const float* lr_t, float beta1, float beta2, float eps) {
+    MPG_REQUIRE(p && grad && m && v && lr_t, "mpg_adam_step: null pointer");
     if (n == 0) return MPG_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, p, grad, m, v, n, lr_t,
                        beta1, beta2, eps);

@@ -61,7 +61,8 @@ class ConvLayerFn(torch.autograd.Function):
         else:
             lin = ops.conv2d_direct(x, w.detach().contiguous(), stride, wscale, None, b, conv_act, leak)
         if bn:
-            y, mean, var = train_ops.bn_train_fwd(lin, gamma, beta, cfg["eps"], act, leak)
+            mm, mv = cfg.get("moving", (None, None))
+            y, mean, var = train_ops.bn_train_fwd(lin, gamma, beta, cfg["eps"], act, leak, mm, mv, cfg.get("decay", 0.999))
             cfg["batch_stats"] = (mean, var)
             ctx.save_for_backward(x, w, lin, mean, var, gamma, y)
         else:
@@ -182,7 +183,6 @@ class TrainSession(object):
         self.bn_decay = bn_decay
         self.device = torch.device(device)
         self.params = {}
-        self._bn_updates = []
 
     def parameters(self):
         """name -> leaf tensor for every variable of the graph (trainable ones require grad)"""
@@ -214,14 +214,9 @@ class TrainSession(object):
         for node, t in feeds.items():
             env[node.id] = torch.as_tensor(t, dtype=torch.float32, device=self.device)
         users = self._count_users(fetches)
-        self._bn_updates = []
-        outs = [self._eval(f, env, users) for f in fetches]
-        # UPDATE_OPS of tf.contrib.layers.batch_norm run with the step (multipassGAN-4x.py:773-776,889-899)
-        with torch.no_grad():
-            for mm, mv, mean, var in self._bn_updates:
-                mm.mul_(self.bn_decay).add_(mean, alpha=1.0 - self.bn_decay)
-                mv.mul_(self.bn_decay).add_(var, alpha=1.0 - self.bn_decay)
-        return outs
+        # the UPDATE_OPS of tf.contrib.layers.batch_norm (multipassGAN-4x.py:773-776,889-899) run inside
+        # mpg_bn_train_fwd: every evaluated batch-norm layer advances its moving averages once
+        return [self._eval(f, env, users) for f in fetches]
 
     def _count_users(self, fetches):
         users, seen, stack = {}, set(), list(fetches)
@@ -334,11 +329,9 @@ class TrainSession(object):
                 raise G.GraphError("TrainSession needs batch_norm(training=True) nodes (build the nets with train=True)")
             gamma = self.params[bn.inputs[1].attrs["var"]]
             beta = self.params[bn.inputs[2].attrs["var"]]
+            cfg["moving"] = (self.params[bn.inputs[3].attrs["var"]], self.params[bn.inputs[4].attrs["var"]])
+            cfg["decay"] = self.bn_decay
         y = ConvLayerFn.apply(x, w4, b, gamma, beta, cfg)
-        if bn is not None:
-            mean, var = cfg["batch_stats"]
-            self._bn_updates.append((self.params[bn.inputs[3].attrs["var"]], self.params[bn.inputs[4].attrs["var"]],
-                                     mean, var))
         return y.reshape(y.shape[0], -1) if is_fc else y
 
 
@@ -362,22 +355,28 @@ class AdamTF(object):
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)       # parameters alias the flat buffer
                 off += k
+        self._grad_views, off = [], 0
+        for p in self.params:
+            self._grad_views.append(self.grad[off:off + p.numel()].view(p.shape))
+            off += p.numel()
         self.lr, self.b1, self.b2, self.eps, self.t = lr, beta1, beta2, eps, 0
+        self.lr_t = torch.zeros(1, dtype=torch.float32, device=dev)      # read by the kernel: replayable in a graph
 
-    def step(self, grads, lr=None):
-        """grads: list aligned with self.params (None = zero gradient, as tf treats unconnected variables)"""
-        off = 0
-        for p, g in zip(self.params, grads):
-            k = p.numel()
-            if g is None:
-                self.grad[off:off + k].zero_()
-            else:
-                self.grad[off:off + k].copy_(g.reshape(-1))
-            off += k
+    def advance(self, lr=None):
+        """host side of a step: t += 1 and the bias-corrected step size into device memory"""
         self.t += 1
         lr = self.lr if lr is None else lr
-        lr_t = lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
-        train_ops.adam_step(self.flat, self.grad, self.m, self.v, lr_t, self.b1, self.b2, self.eps)
+        self.lr_t.fill_(lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t))
+
+    def step(self, grads, lr=None, advance=True):
+        """grads: list aligned with self.params (None = zero gradient, as tf treats unconnected variables)"""
+        if advance:
+            self.advance(lr)
+        if any(g is None for g in grads):
+            self.grad.zero_()
+        dst = [v for v, g in zip(self._grad_views, grads) if g is not None]
+        torch._foreach_copy_(dst, [g.contiguous() for g in grads if g is not None])
+        train_ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr_t, self.b1, self.b2, self.eps)
 
 
 def sigmoid_ce(logits, label):
@@ -443,22 +442,57 @@ class Trainer4x(object):
         L["gen_part"] = gen_part
         return L
 
-    def disc_step(self, batch_xs, batch_ys):
+    def disc_step(self, batch_xs, batch_ys, advance=True):
         L = self.losses(batch_xs, batch_ys)
         grads = torch.autograd.grad(L["disc_loss"], self.opt_d.params, allow_unused=True)
-        self.opt_d.step(grads)
+        self.opt_d.step(grads, advance=advance)
         return L
 
-    def gen_step(self, batch_xs, batch_ys):
+    def gen_step(self, batch_xs, batch_ys, advance=True):
         L = self.losses(batch_xs, batch_ys)
         grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
-        self.opt_g.step(grads)
+        self.opt_g.step(grads, advance=advance)
         return L
 
+    def train_step_graphed(self, batch_xs, batch_ys):
+        """the same iteration (discRuns = genRuns = 1) replayed from one captured hipGraph: ~1500 launches
+        of the eager step become one graph launch.  Shapes are fixed by the first call; every later
+        call copies the batch into the static inputs, bumps the Adam step sizes in device memory and
+        replays.  Returns (disc_loss, gen_loss_complete) device scalars of the replayed iteration."""
+        dev = self.opt_d.flat.device
+        xs = torch.as_tensor(batch_xs, dtype=torch.float32, device=dev)
+        ys = torch.as_tensor(batch_ys, dtype=torch.float32, device=dev)
+        if getattr(self, "_graph", None) is None:
+            self._gx, self._gy = xs.clone(), ys.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.train_step(self._gx, self._gy)        # allocator / lazy initialisation warm-up
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            self.opt_d.advance()
+            self.opt_g.advance()
+            with torch.cuda.graph(self._graph):
+                Ld = self.disc_step(self._gx, self._gy, advance=False)
+                Lg = self.gen_step(self._gx, self._gy, advance=False)
+                self._gout = (Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach())
+            self._graph.replay()       # capture does not execute: run the captured iteration once
+            return self._gout
+        if xs.shape != self._gx.shape or ys.shape != self._gy.shape:
+            raise _lib.MpgError("train_step_graphed: batch shape changed after capture")
+        self._gx.copy_(xs)
+        self._gy.copy_(ys)
+        self.opt_d.advance()
+        self.opt_g.advance()
+        self._graph.replay()
+        return self._gout
+
     def train_step(self, batch_xs, batch_ys, discRuns=1, genRuns=1):
-        """one iteration of the reference loop (:1317-1356): returns (disc_loss, gen_loss_complete) as floats"""
+        """one iteration of the reference loop (:1317-1356): returns (disc_loss, gen_loss_complete) device scalars"""
         for _ in range(discRuns):
             Ld = self.disc_step(batch_xs, batch_ys)
         for _ in range(genRuns):
             Lg = self.gen_step(batch_xs, batch_ys)
-        return Ld["disc_loss"], Lg["gen_loss_complete"]
+        # detached: holding a loss would keep the tape (and its stream bookkeeping) alive across iterations
+        return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()

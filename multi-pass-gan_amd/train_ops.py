@@ -85,17 +85,19 @@ def channel_sum(x):
     return out
 
 
-def bn_train_fwd(x, gamma, beta, eps=1e-3, act=None, leak=0.2):
-    """-> (y, batch_mean, batch_var[biased])"""
+def bn_train_fwd(x, gamma, beta, eps=1e-3, act=None, leak=0.2, moving_mean=None, moving_var=None, decay=0.999):
+    """-> (y, batch_mean, batch_var[biased]); advances moving_mean / moving_var in place when given"""
     lib = _lib.load()
     x = _cont(x, "x")
     c = x.shape[-1]
     y = torch.empty_like(x)
-    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
-    var = torch.empty((c,), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    mean, var = stats[0], stats[1]
+    mm = _dev(moving_mean, "moving_mean") if moving_mean is not None else None
+    mv = _dev(moving_var, "moving_var") if moving_var is not None else None
     _lib.check(lib.mpg_bn_train_fwd(_stream(), _ptr(x), x.numel() // c, c, _ptr(_cont(gamma, "gamma")),
                                     _ptr(_cont(beta, "beta")), float(eps), _lib.act_id(act), leak, _ptr(y), _ptr(mean),
-                                    _ptr(var)), "mpg_bn_train_fwd")
+                                    _ptr(var), _ptr(mm), _ptr(mv), float(decay)), "mpg_bn_train_fwd")
     return y, mean, var
 
 
@@ -105,8 +107,8 @@ def bn_train_bwd(dy, x, mean, var, gamma, eps=1e-3):
     dy, x = _cont(dy, "dy"), _cont(x, "x")
     c = x.shape[-1]
     dx = torch.empty_like(x)
-    dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
-    dbeta = torch.empty((c,), dtype=torch.float32, device=x.device)
+    dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    dgamma, dbeta = dgb[0], dgb[1]
     _lib.check(lib.mpg_bn_train_bwd(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, _ptr(mean), _ptr(var),
                                     _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta)),
                "mpg_bn_train_bwd")
@@ -161,11 +163,13 @@ def lerp(x, y, t):
 
 
 def adam_step(p, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
-    """in-place tf.train.AdamOptimizer update of the flat fp32 buffer p"""
+    """in-place tf.train.AdamOptimizer update of the flat fp32 buffer p; lr_t is a 1-element GPU tensor"""
     lib = _lib.load()
-    for t, nm in ((p, "p"), (grad, "grad"), (m, "m"), (v, "v")):
+    if not isinstance(lr_t, torch.Tensor):
+        lr_t = torch.full((1,), float(lr_t), dtype=torch.float32, device=p.device)
+    for t, nm in ((p, "p"), (grad, "grad"), (m, "m"), (v, "v"), (lr_t, "lr_t")):
         _dev(t, nm)
         if not t.is_contiguous():
             raise _lib.MpgError("adam_step: %s must be contiguous" % nm)
-    _lib.check(lib.mpg_adam_step(_stream(), _ptr(p), _ptr(grad), _ptr(m), _ptr(v), p.numel(), float(lr_t), float(beta1),
+    _lib.check(lib.mpg_adam_step(_stream(), _ptr(p), _ptr(grad), _ptr(m), _ptr(v), p.numel(), _ptr(lr_t), float(beta1),
                                  float(beta2), float(eps)), "mpg_adam_step")

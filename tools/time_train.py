@@ -26,3 +26,13 @@ torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
 print("tile %d batch %d: %.2f ms / iteration (%.1f it/s, %.0f tiles/s) disc_loss %.4f gen_loss %.4f"
       % (tile, batch, dt * 1e3, 1 / dt, batch / dt, float(d.detach()), float(g.detach())))
+for _ in range(2):
+    tr.train_step_graphed(xs, ys)
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(steps):
+    d, g = tr.train_step_graphed(xs, ys)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / steps
+print("  hipGraph replay: %.2f ms / iteration (%.1f it/s, %.0f tiles/s) disc_loss %.4f gen_loss %.4f"
+      % (dt * 1e3, 1 / dt, batch / dt, float(d), float(g)))
