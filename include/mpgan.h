@@ -240,6 +240,9 @@ int mpg_resize_nearest_bwd(mpg_stream_t stream, const float* dy, int n, int oh, 
 int mpg_avg_pool2_bwd(mpg_stream_t stream, const float* dy, int n, int h, int w, int c, float* dx);
 /* lerp(x, y, t) = x + (y - x) * t with t already clipped to [0,1] (multipassGAN-8x.py:598-599); x NULL = zeros */
 int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, size_t n, float t, float* out);
+/* the reductions of the generator losses (multipassGAN-4x.py:754,764-765): out[0] = sum |a - b| (mode 0,
+ * tf.reduce_mean(tf.abs(..)) after division by n) or sum (a - b)^2 (mode 1, 2 * tf.nn.l2_loss); b NULL = 0 */
+int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out);
 /* tf.train.AdamOptimizer update on a flat parameter buffer (multipassGAN-4x.py:880-902):
  * m += (g-m)(1-b1); v += (g*g-v)(1-b2); p -= lr_t * m / (sqrt(v) + eps), with
  * lr_t = lr * sqrt(1-b2^t)/(1-b1^t) computed by the caller and read from DEVICE memory (one float),

@@ -36,3 +36,18 @@ extern "C" int mpg_device_info(int* cu_count, char* arch_name, int arch_name_len
     }
     return MPG_OK;
 }
+
+namespace {
+__global__ void zero_words_kernel(unsigned int* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+
+hipError_t mpg::zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned int*)ptr, n);
+    return hipGetLastError();
+}

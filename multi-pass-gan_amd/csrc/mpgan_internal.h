@@ -28,6 +28,12 @@ inline int hip_check(hipError_t e, const char* what) {
 
 #define MPG_LAUNCH_CHECK(name) return mpg::hip_check(hipGetLastError(), name)
 
+// Zero `bytes` (a multiple of 4) of device memory with a kernel on `stream`.  Used instead of
+// hipMemsetAsync for buffers that atomics accumulate into: memset nodes of a captured hipGraph were
+// observed to lose their ordering against the neighbouring kernels on replay (ROCm 7.2), a plain
+// kernel node does not.
+hipError_t zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 __device__ __forceinline__ float apply_act(float v, int act, float leak) {
     // MPG_ACT_RELU: tf.nn.relu; MPG_ACT_LRELU: 0.5(1+leak) x + 0.5(1-leak)|x| (GAN.py:733-737)
     if (act == MPG_ACT_RELU) return fmaxf(v, 0.f);

@@ -371,6 +371,24 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// out[0] += sum_i |a_i - b_i| (mode 0) or sum_i (a_i - b_i)^2 (mode 1); block partials, one atomic per block
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          size_t n, int mode, float* __restrict__ out) {
+    __shared__ float red[BLK];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) {
+        const float d = a[i] - (b ? b[i] : 0.f);
+        s += mode == 0 ? fabsf(d) : d * d;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
 int fill_geom(ConvGeom& g, int n, int h, int w, int cin, int cout, int kh, int kw, int sh, int sw) {
     g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw;
     g.oh = (h + sh - 1) / sh;
@@ -396,7 +414,7 @@ extern "C" int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int 
     ConvGeom g;
     fill_geom(g, n, h, w, cin, cout, kh, kw, stride_h, stride_w);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad: memset");
     const int mi = micro(cin), ni = micro(cout);
 #define MPG_WG(M, N) if (mi == M && ni == N) launch_wgrad<M, N>(s, x, dy, dw, g, wscale)
@@ -435,7 +453,7 @@ extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix,
     MPG_REQUIRE(x && out, "mpg_channel_sum: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_channel_sum: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)c * sizeof(float), s);
+    hipError_t e = mpg::zero_async(out, (size_t)c * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_channel_sum: memset");
     launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, out, nullptr);
     MPG_LAUNCH_CHECK("chan_sum_kernel");
@@ -450,10 +468,10 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (batch_var == batch_mean + c) {
-        e = hipMemsetAsync(batch_mean, 0, (size_t)2 * c * sizeof(float), s);
+        e = mpg::zero_async(batch_mean, (size_t)2 * c * sizeof(float), s);
     } else {
-        e = hipMemsetAsync(batch_mean, 0, (size_t)c * sizeof(float), s);
-        if (e == hipSuccess) e = hipMemsetAsync(batch_var, 0, (size_t)c * sizeof(float), s);
+        e = mpg::zero_async(batch_mean, (size_t)c * sizeof(float), s);
+        if (e == hipSuccess) e = mpg::zero_async(batch_var, (size_t)c * sizeof(float), s);
     }
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
     const float inv_n = 1.f / (float)npix;
@@ -476,10 +494,10 @@ extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const floa
     hipStream_t s = (hipStream_t)stream;
     hipError_t e;
     if (dbeta == dgamma + c) {
-        e = hipMemsetAsync(dgamma, 0, (size_t)2 * c * sizeof(float), s);
+        e = mpg::zero_async(dgamma, (size_t)2 * c * sizeof(float), s);
     } else {
-        e = hipMemsetAsync(dgamma, 0, (size_t)c * sizeof(float), s);
-        if (e == hipSuccess) e = hipMemsetAsync(dbeta, 0, (size_t)c * sizeof(float), s);
+        e = mpg::zero_async(dgamma, (size_t)c * sizeof(float), s);
+        if (e == hipSuccess) e = mpg::zero_async(dbeta, (size_t)c * sizeof(float), s);
     }
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
     launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
@@ -532,6 +550,19 @@ extern "C" int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, siz
     if (n == 0) return MPG_OK;
     hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, x, y, n, t, out);
     MPG_LAUNCH_CHECK("lerp_kernel");
+}
+
+extern "C" int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out) {
+    MPG_REQUIRE(a && out, "mpg_pair_reduce: null pointer");
+    MPG_REQUIRE(mode == 0 || mode == 1, "mpg_pair_reduce: mode %d", mode);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = mpg::zero_async(out, sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_pair_reduce: zero");
+    if (n == 0) return MPG_OK;
+    size_t blocks = (n + BLK * 8 - 1) / (BLK * 8);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3((unsigned)blocks), dim3(BLK), 0, s, a, b, n, mode, out);
+    MPG_LAUNCH_CHECK("pair_reduce_kernel");
 }
 
 extern "C" int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, size_t n,

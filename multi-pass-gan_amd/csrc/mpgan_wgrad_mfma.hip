@@ -311,8 +311,8 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     float* amax = (float*)workspace;
     _Float16* xp = (_Float16*)((char*)workspace + 256);
     _Float16* dp = xp + p16_elems(n, h, w, cin);
-    hipError_t e = hipMemsetAsync(amax, 0, 256, s);
-    if (e == hipSuccess) e = hipMemsetAsync(dw, 0, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    hipError_t e = mpg::zero_async(amax, 256, s);
+    if (e == hipSuccess) e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nx + BLK * 8 - 1) / (BLK * 8) > 1024 ? 1024 : (nx + BLK * 8 - 1) / (BLK * 8))),

@@ -103,6 +103,22 @@ class ConvLayerFn(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None
 
 
+def space_to_depth2(x):
+    """[N,H,W,C] -> [N,H/2,W/2,4C], channel (r*2+s)*C + c holds x[2Y+r, 2X+s, c]"""
+    n, h, w, c = x.shape
+    return x.reshape(n, h // 2, 2, w // 2, 2, c).permute(0, 1, 3, 2, 4, 5).reshape(n, h // 2, w // 2, 4 * c)
+
+
+def strided4_as_3x3(w):
+    """The 4x4 stride-2 SAME filter of the discriminators (multipassGAN-4x.py:607-613) as a 3x3 stride-1
+    filter over the space-to-depth input: y[Y,X] = sum_{a,b,r,s} z[Y+a-1, X+b-1, (r,s,c)] * W[2a+r-1, 2b+s-1, c]
+    (taps outside 0..3 are zero).  With it the strided convs, their data and weight gradients all run on
+    the matrix-core kernels; 16 of the 36 (a,b,r,s) positions carry weights."""
+    kh, kw, c, co = w.shape
+    wp = torch.nn.functional.pad(w, (0, 0, 0, 0, 1, 1, 1, 1))            # zero ring: [6,6,C,Co]
+    return wp.reshape(3, 2, 3, 2, c, co).permute(0, 2, 1, 3, 4, 5).reshape(3, 3, 4 * c, co)
+
+
 class ActFn(torch.autograd.Function):
     """act(a [+ b]) (tf.nn.relu(tf.add(B, s)), multipassGAN-4x.py:523)"""
 
@@ -172,6 +188,24 @@ class LerpFn(torch.autograd.Function):
         return dx, dxy, None
 
 
+class PairLossFn(torch.autograd.Function):
+    """sum |a - b| (mode 0) / sum (a - b)^2 (mode 1) with the reduction in ``mpg_pair_reduce``; the
+    backward is elementwise"""
+
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        ctx.save_for_backward(a, b)
+        ctx.mode = mode
+        return train_ops.pair_reduce(a, b, mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        d = a - b
+        ga = (torch.sign(d) if ctx.mode == 0 else 2.0 * d) * g
+        return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None), None
+
+
 class TrainSession(object):
     """Eager, differentiable evaluation of ``graph`` nodes; parameters are leaf tensors keyed by
     the TF variable path.  ``run(fetches, feeds)`` returns torch tensors that carry the tape."""
@@ -182,6 +216,7 @@ class TrainSession(object):
         self.prec = prec
         self.bn_decay = bn_decay
         self.device = torch.device(device)
+        self.strided_on_mfma = True      # 4x4 stride-2 convs as 3x3 stride-1 convs over space-to-depth inputs
         self.params = {}
 
     def parameters(self):
@@ -321,6 +356,9 @@ class TrainSession(object):
             stride = (1, 1)
         else:
             w4, stride = w, tuple(conv.attrs["stride"])
+            if stride == (2, 2) and tuple(w.shape[:2]) == (4, 4) and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 \
+                    and self.strided_on_mfma:
+                x, w4, stride = space_to_depth2(x), strided4_as_3x3(w), (1, 1)
         cfg = {"stride": stride, "wscale": conv.attrs["wscale"], "act": act, "leak": leak, "prec": self.prec, "fc": is_fc,
                "eps": bn.attrs["eps"] if bn is not None else 0.0}
         gamma = beta = None
@@ -432,12 +470,12 @@ class Trainer4x(object):
         L["disc_loss_gen"] = sigmoid_ce(gen, zeros)
         layer = 0.0
         for kf, a, b in zip(self.k2_l, (dy1, dy2, dy3, dy4), (gy1, gy2, gy3, gy4)):
-            layer = layer + kf * 0.5 * ((a - b) ** 2).sum()          # tf.nn.l2_loss
+            layer = layer + (kf * 0.5) * PairLossFn.apply(a, b, 1)   # tf.nn.l2_loss
         L["disc_loss_layer"] = layer
         L["disc_loss"] = L["disc_loss_disc"] * self.weight_dld + L["disc_loss_gen"]
         L["gen_loss"] = sigmoid_ce(gen, ones)
-        L["gen_l2_loss"] = 0.5 * ((y - gen_part) ** 2).sum()
-        L["gen_l1_loss"] = (y - gen_part).abs().mean()
+        L["gen_l2_loss"] = 0.5 * PairLossFn.apply(y, gen_part, 1)
+        L["gen_l1_loss"] = PairLossFn.apply(y, gen_part, 0) / float(gen_part.numel())
         L["gen_loss_complete"] = L["gen_loss"] + L["gen_l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
         L["gen_part"] = gen_part
         return L

@@ -162,6 +162,16 @@ def lerp(x, y, t):
     return out
 
 
+def pair_reduce(a, b, mode):
+    """0-dim tensor: sum |a - b| (mode 0) or sum (a - b)^2 (mode 1)"""
+    lib = _lib.load()
+    a = _cont(a, "a")
+    b = _cont(b, "b") if b is not None else None
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    _lib.check(lib.mpg_pair_reduce(_stream(), _ptr(a), _ptr(b), a.numel(), mode, _ptr(out)), "mpg_pair_reduce")
+    return out
+
+
 def adam_step(p, grad, m, v, lr_t, beta1, beta2, eps=1e-8):
     """in-place tf.train.AdamOptimizer update of the flat fp32 buffer p; lr_t is a 1-element GPU tensor"""
     lib = _lib.load()
