@@ -31,6 +31,14 @@ class Comm(object):
         dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
         return full
 
+    def all_reduce_mean(self, flat):
+        """data-parallel training: average one flat gradient buffer (one bucket per optimiser) in place"""
+        if self.world == 1:
+            return flat
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world)
+        return flat
+
     def barrier(self):
         dist.barrier(group=self.group)
 

@@ -18,6 +18,9 @@ class GraphError(Exception):
     pass
 
 
+_default_graph = []
+
+
 class Node(object):
     """A symbolic NHWC tensor.  ``shape`` uses None for the unknown batch size."""
 
@@ -31,6 +34,7 @@ class Node(object):
         Node._counter[0] += 1
         self.id = Node._counter[0]
         self.name = attrs.get("name") or "%s_%d" % (op, self.id)
+        self.scope = _default_graph[0].scope_name() if _default_graph else ""     # variable scope at creation
 
     def get_shape(self):
         return _Shape(self.shape)
@@ -78,7 +82,7 @@ class Graph(object):
         return Node("variable", shape=spec.shape, var=spec.name, name=spec.name)
 
 
-_default_graph = [Graph()]
+_default_graph.append(Graph())
 
 
 def get_default_graph():
@@ -195,6 +199,39 @@ def activation_name(fn):
     if nm in ("relu", "lrelu", "tanh"):
         return nm
     raise GraphError("unsupported activation function %r" % (fn,))
+
+
+class Scalar(object):
+    """A fed scalar plus a constant (``percentage - (j - 1)`` of the growing nets, multipassGAN-8x.py:828-833):
+    the blend factors are read from the feed at run time, so one graph serves every training iteration."""
+
+    def __init__(self, node, offset=0.0):
+        self.node, self.offset = node, float(offset)
+
+    def __sub__(self, k):
+        return Scalar(self.node, self.offset - float(k))
+
+    def __add__(self, k):
+        return Scalar(self.node, self.offset + float(k))
+
+    def value(self, feeds):
+        for k, v in feeds.items():
+            if k is self.node:
+                return float(v) + self.offset
+        raise GraphError("scalar %r was not fed" % (self.node,))
+
+
+def scalar_placeholder(name=None):
+    """tf.placeholder(tf.float32) for a scalar such as `percentage` (multipassGAN-8x.py:1018)"""
+    return Scalar(Node("scalar", shape=(), name=name))
+
+
+def lerp(x, y, t):
+    """lerp(x, y, t) = x + (y - x) * clip(t, 0, 1) (multipassGAN-8x.py:598-599).  x None stands for
+    tf.zeros_like(y); t is a float or a ``Scalar``."""
+    if x is not None and tuple(x.shape[1:]) != tuple(y.shape[1:]):
+        raise GraphError("lerp: shapes %s and %s differ" % (x.shape, y.shape))
+    return Node("lerp", [y] if x is None else [x, y], shape=y.shape, t=t, zero_x=x is None)
 
 
 def pixel_norm(x, epsilon=1e-8):

@@ -103,6 +103,176 @@ class ConvLayerFn(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None
 
 
+# ----------------------------------------------------------------------------------------------
+# Layers whose backward is itself differentiable (WGAN-GP: the gradient penalty of multipassGAN-8x.py
+# :1123-1140 differentiates |dD/dx| with respect to the discriminator weights).  Convolution, its data
+# gradient and its weight gradient are closed under differentiation:
+#   y  = conv(x, w)      : dx = dgrad(dy, w)     dw = wgrad(x, dy)
+#   dx = dgrad(dy, w)    : d(dy) = conv(g, w)    dw = wgrad(g, dy)
+#   dw = wgrad(x, dy)    : dx = dgrad(dy, G)     d(dy) = conv(x, G)
+# so three Functions that call each other give gradients of any order from the same kernels.
+# ----------------------------------------------------------------------------------------------
+def _conv_fwd(x, w, b, cfg):
+    kh, kw, cin, cout = w.shape
+    if cfg.get("fc"):
+        return train_ops.fc_forward(x.reshape(x.shape[0], cin), w.reshape(cin, cout), cfg["wscale"], b).reshape(
+            x.shape[0], 1, 1, cout)
+    if _mfma_ok(kh, kw, cout, cfg["stride"]):
+        return _mfma_conv(x.contiguous(), w.contiguous(), cfg["wscale"], cfg["prec"], b)
+    return ops.conv2d_direct(x.contiguous(), w.contiguous(), cfg["stride"], cfg["wscale"], None, b)
+
+
+def _conv_dgrad(dy, w, cfg, hw):
+    kh, kw, cin, cout = w.shape
+    if _mfma_ok(kh, kw, cin, cfg["stride"]) and not cfg.get("fc"):
+        return _mfma_conv(dy.contiguous(), w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), cfg["wscale"], cfg["prec"],
+                          pad_hi=1)
+    return train_ops.conv2d_dgrad(dy, w, hw, cfg["stride"], cfg["wscale"])
+
+
+def _conv_wgrad(x, dy, cfg, kh, kw):
+    if train_ops.wgrad_mfma_ok(kh, kw, cfg["stride"]) and not cfg.get("fc"):
+        return train_ops.conv2d_wgrad_mfma(x, dy, kh, kw, cfg["wscale"], cfg["prec"])
+    return train_ops.conv2d_wgrad(x, dy, kh, kw, cfg["stride"], cfg["wscale"])
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv2d_SAME(x, w * wscale) + b, differentiable to any order"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        ctx.save_for_backward(x, w)
+        ctx.cfg, ctx.has_bias = cfg, b is not None
+        return _conv_fwd(x.detach(), w.detach(), b.detach() if b is not None else None, cfg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = ConvDgradFn.apply(dy, w, ctx.cfg, (x.shape[1], x.shape[2])) if ctx.needs_input_grad[0] else None
+        dw = ConvWgradFn.apply(x, dy, ctx.cfg, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        db = train_ops.channel_sum(dy.detach()) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None
+
+
+class ConvDgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, w, cfg, hw):
+        ctx.save_for_backward(dy, w)
+        ctx.cfg = cfg
+        return _conv_dgrad(dy.detach(), w.detach(), cfg, hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        dy, w = ctx.saved_tensors
+        ddy = ConvFn.apply(g, w, None, ctx.cfg) if ctx.needs_input_grad[0] else None
+        dw = ConvWgradFn.apply(g, dy, ctx.cfg, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
+        return ddy, dw, None, None
+
+
+class ConvWgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dy, cfg, kh, kw):
+        ctx.save_for_backward(x, dy)
+        ctx.cfg = cfg
+        return _conv_wgrad(x.detach(), dy.detach(), cfg, kh, kw)
+
+    @staticmethod
+    def backward(ctx, gw):
+        x, dy = ctx.saved_tensors
+        dx = ConvDgradFn.apply(dy, gw, ctx.cfg, (x.shape[1], x.shape[2])) if ctx.needs_input_grad[0] else None
+        ddy = ConvFn.apply(x, gw, None, ctx.cfg) if ctx.needs_input_grad[1] else None
+        return dx, ddy, None, None, None
+
+
+class ActBwdFn(torch.autograd.Function):
+    """dx = dy * act'(.) with the mask taken from the activation output: linear in dy"""
+
+    @staticmethod
+    def forward(ctx, dy, y, act, leak):
+        ctx.save_for_backward(y)
+        ctx.act, ctx.leak = act, leak
+        return train_ops.act_bwd(dy.detach(), y, act, leak)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(g, y, ctx.act, ctx.leak), None, None, None
+
+
+class Act2Fn(torch.autograd.Function):
+    """act(x) for relu / lrelu (piecewise linear: the second derivative is zero almost everywhere)"""
+
+    @staticmethod
+    def forward(ctx, x, act, leak):
+        y = ops.add_act(x.detach().contiguous(), None, act, leak)
+        ctx.save_for_backward(y)
+        ctx.act, ctx.leak = act, leak
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(dy, y, ctx.act, ctx.leak), None, None
+
+
+class AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return ops.avg_pool2(x.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return AvgPoolBwd2Fn.apply(dy, ctx.hw)
+
+
+class AvgPoolBwd2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, hw):
+        return train_ops.avg_pool2_bwd(dy.detach(), *hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        return AvgPool2Fn.apply(g), None
+
+
+class ResizeNearest2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, oh, ow):
+        ctx.hw, ctx.ohw = (x.shape[1], x.shape[2]), (oh, ow)
+        return ops.resize_nearest(x.detach().contiguous(), oh, ow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ResizeNearestBwd2Fn.apply(dy, ctx.hw), None, None
+
+
+class ResizeNearestBwd2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, hw):
+        ctx.ohw = (dy.shape[1], dy.shape[2])
+        return train_ops.resize_nearest_bwd(dy.detach(), *hw)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ResizeNearest2Fn.apply(g, *ctx.ohw), None
+
+
+class Lerp2Fn(torch.autograd.Function):
+    """lerp with a backward made of lerps (linear in both operands)"""
+
+    @staticmethod
+    def forward(ctx, x, y, t):
+        ctx.t, ctx.has_x = min(max(float(t), 0.0), 1.0), x is not None
+        return train_ops.lerp(x.detach() if x is not None else None, y.detach(), ctx.t)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dyy = Lerp2Fn.apply(None, dy, ctx.t) if ctx.needs_input_grad[1] else None
+        dx = Lerp2Fn.apply(None, dy, 1.0 - ctx.t) if (ctx.has_x and ctx.needs_input_grad[0]) else None
+        return dx, dyy, None
+
+
 def space_to_depth2(x):
     """[N,H,W,C] -> [N,H/2,W/2,4C], channel (r*2+s)*C + c holds x[2Y+r, 2X+s, c]"""
     n, h, w, c = x.shape
@@ -217,7 +387,10 @@ class TrainSession(object):
         self.bn_decay = bn_decay
         self.device = torch.device(device)
         self.strided_on_mfma = True      # 4x4 stride-2 convs as 3x3 stride-1 convs over space-to-depth inputs
+        # variable-name prefixes whose layers must support gradients of gradients (the WGAN-GP discriminators)
+        self.higher_order_scopes = ()
         self.params = {}
+        self._scalar_feeds = {}
 
     def parameters(self):
         """name -> leaf tensor for every variable of the graph (trainable ones require grad)"""
@@ -246,8 +419,12 @@ class TrainSession(object):
             raise _lib.MpgError("no GPU visible: the training step has no CPU fallback")
         self.parameters()
         env = {}
+        self._scalar_feeds = {}
         for node, t in feeds.items():
-            env[node.id] = torch.as_tensor(t, dtype=torch.float32, device=self.device)
+            if isinstance(node, G.Scalar):
+                self._scalar_feeds[node.node] = float(t)
+            else:
+                env[node.id] = torch.as_tensor(t, dtype=torch.float32, device=self.device)
         users = self._count_users(fetches)
         # the UPDATE_OPS of tf.contrib.layers.batch_norm (multipassGAN-4x.py:773-776,889-899) run inside
         # mpg_bn_train_fwd: every evaluated batch-norm layer advances its moving averages once
@@ -291,6 +468,10 @@ class TrainSession(object):
             return None
         return cur, bias, bn, act, leak
 
+    def _higher(self, n):
+        """does this node sit in a variable scope that needs differentiable backward passes?"""
+        return any(n.scope.startswith(p) for p in self.higher_order_scopes)
+
     def _eval(self, n, env, users):
         if n.id in env:
             return env[n.id]
@@ -330,14 +511,17 @@ class TrainSession(object):
         if op == "pixel_norm":
             return PixelNormFn.apply(ev(n.inputs[0]), n.attrs["eps"])
         if op == "avg_pool":
-            return AvgPoolFn.apply(ev(n.inputs[0]))
+            return (AvgPool2Fn if self._higher(n) else AvgPoolFn).apply(ev(n.inputs[0]))
         if op == "lerp":
-            x = ev(n.inputs[0]) if n.inputs[0] is not None else None
-            return LerpFn.apply(x, ev(n.inputs[1]), n.attrs["t"])
+            t = n.attrs["t"]
+            t = t.value(self._scalar_feeds) if isinstance(t, G.Scalar) else float(t)
+            x = None if n.attrs["zero_x"] else ev(n.inputs[0])
+            y = ev(n.inputs[-1])
+            return (Lerp2Fn if self._higher(n) else LerpFn).apply(x, y, t)
         if op == "resize":
             x = ev(n.inputs[0])
             if n.attrs["method"] == 1:
-                return ResizeNearestFn.apply(x, n.attrs["oh"], n.attrs["ow"])
+                return (ResizeNearest2Fn if self._higher(n) else ResizeNearestFn).apply(x, n.attrs["oh"], n.attrs["ow"])
             if x.requires_grad:
                 raise NotImplementedError("gradient of bilinear / bicubic resize (only applied to network inputs)")
             return ops.resize_images(x.contiguous(), n.attrs["oh"], n.attrs["ow"], n.attrs["method"])
@@ -361,6 +545,16 @@ class TrainSession(object):
                 x, w4, stride = space_to_depth2(x), strided4_as_3x3(w), (1, 1)
         cfg = {"stride": stride, "wscale": conv.attrs["wscale"], "act": act, "leak": leak, "prec": self.prec, "fc": is_fc,
                "eps": bn.attrs["eps"] if bn is not None else 0.0}
+        wname = conv.inputs[1].attrs["var"]
+        if any(wname.startswith(p) for p in self.higher_order_scopes):
+            if bn is not None:
+                raise G.GraphError("batch norm inside a gradient-penalty network is not built (the 8x discriminators have none)")
+            y = ConvFn.apply(x, w4, b, cfg)
+            if act is not None:
+                if act == "tanh":
+                    raise G.GraphError("tanh has no higher-order lowering")
+                y = Act2Fn.apply(y, act, leak)
+            return y.reshape(y.shape[0], -1) if is_fc else y
         gamma = beta = None
         if bn is not None:
             if not bn.attrs["training"]:
@@ -377,7 +571,8 @@ class AdamTF(object):
     """tf.train.AdamOptimizer(lr, beta1, beta2=0.999, epsilon=1e-8) over a set of leaf tensors, one
     flat fp32 buffer per optimiser: p -= lr_t * m / (sqrt(v) + eps) (``mpg_adam_step``)."""
 
-    def __init__(self, params, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8):
+    def __init__(self, params, lr=2e-4, beta1=0.5, beta2=0.999, eps=1e-8, comm=None):
+        self.comm = comm        # dist.Comm: gradients are averaged over the ranks before the update (one bucket)
         self.names = sorted(params)
         self.params = [params[n] for n in self.names]
         n = sum(p.numel() for p in self.params)
@@ -414,6 +609,8 @@ class AdamTF(object):
             self.grad.zero_()
         dst = [v for v, g in zip(self._grad_views, grads) if g is not None]
         torch._foreach_copy_(dst, [g.contiguous() for g in grads if g is not None])
+        if self.comm is not None:
+            self.comm.all_reduce_mean(self.grad)
         train_ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr_t, self.b1, self.b2, self.eps)
 
 
@@ -533,4 +730,114 @@ class Trainer4x(object):
         for _ in range(genRuns):
             Lg = self.gen_step(batch_xs, batch_ys)
         # detached: holding a loss would keep the tape (and its stream bookkeeping) alive across iterations
+        return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()
+
+
+class Trainer8x(object):
+    """One stage of the progressive-growing training of multipassGAN-8x.py (graph :1023-1144, optimisers
+    :1305-1362): WGAN-GP (lambda 10, target 1, epsilon penalty 1e-3) or LSGAN or sigmoid-CE losses, L1 and
+    layer losses for the generator, Adam(beta1, beta2) per network, and the 0.999 moving average of the
+    generator weights (tf.contrib.opt.MovingAverageOptimizer).  ``percentage`` in [0, log2(upRes)] is fed per
+    step (3.0 = the final 8x stage).  The temporal discriminator branch is not built."""
+
+    def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
+                 k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
+                 prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999):
+        from . import nets8x
+        from .session import VariableStore
+        self.cfg = cfg
+        self.k, self.k2, self.weight_dld = lambda_l1, lambda2, weight_dld
+        self.use_wgan_gp, self.use_LSGAN = use_wgan_gp, use_LSGAN
+        if use_wgan_gp:
+            self.wgan_lambda, self.wgan_target, self.wgan_epsilon = (150.0, 30.0, 1e-3) if use_LSGAN else (10.0, 1.0, 1e-3)
+        self.currentUpres = int(round(math.log(cfg.upRes, 2)))
+        g = G.reset_default_graph()
+        self.graph = g
+        self.percentage = G.scalar_placeholder("percentage")
+        self.x = G.placeholder([None, cfg.n_input], name="x")
+        self.x_disc = G.placeholder([None, cfg.n_input], name="x_disc")
+        self.y_in = G.placeholder([None, cfg.n_output], name="y_in")
+        self.y_gp = G.placeholder([None, cfg.n_output], name="y_gp")
+        self.gen_y = nets8x.growing_gen(self.x, self.percentage, cfg, train=True, currentUpres=self.currentUpres)
+        dk = dict(cfg=cfg, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
+        self.disc, self.f_y = nets8x.growing_disc(self.y_in, self.x_disc, self.percentage, reuse=False, **dk)
+        self.gen, self.f_g = nets8x.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
+        self.d_out, _ = nets8x.growing_disc(self.y_gp, self.x_disc, self.percentage, reuse=True, **dk)
+        self.k2_ls = list(k2_ls) if k2_ls is not None else [1.0] * len(self.f_y)
+        self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, device=device)
+        if use_wgan_gp:
+            self.sess.higher_order_scopes = ("spatial-disc",)
+        self.g_var = self.sess.trainable("g_")
+        self.d_var = self.sess.trainable("d_")
+        self.opt_d = AdamTF(self.d_var, learning_rate, beta1, beta2, comm=comm)
+        self.opt_g = AdamTF(self.g_var, learning_rate, beta1, beta2, comm=comm)
+        self.ema_decay = ema_decay
+        self.ema = [p.detach().clone() for p in self.opt_g.params]
+        self.rng = torch.Generator(device="cpu").manual_seed(seed)
+
+    # ------------------------------------------------------------------ losses
+    def _adv(self, logits, real):
+        """(discriminator term, generator term) of one critic output"""
+        if self.use_LSGAN:
+            tgt = 1.0 if real else 0.0
+            return 0.5 * ((logits - tgt) ** 2).mean()
+        if self.use_wgan_gp:
+            return (-logits).mean() if real else logits.mean()
+        return sigmoid_ce(logits, torch.ones_like(logits) if real else torch.zeros_like(logits))
+
+    def losses(self, batch_xs, batch_ys, percentage=3.0, lerp_factor=None, need_gp=True):
+        """-> dict of loss tensors (multipassGAN-8x.py:1082-1142); batch_ys at full tileSizeHigh resolution"""
+        dev = self.sess.device
+        xs = torch.as_tensor(batch_xs, dtype=torch.float32, device=dev)
+        ys = torch.as_tensor(batch_ys, dtype=torch.float32, device=dev)
+        feeds = {self.x: xs, self.x_disc: xs, self.y_in: ys, self.percentage: percentage}
+        out = self.sess.run([self.gen_y, self.disc, self.gen] + list(self.f_y) + list(self.f_g), feeds)
+        nf = len(self.f_y)
+        gen_y, disc, gen = out[0], out[1], out[2]
+        f_y, f_g = out[3:3 + nf], out[3 + nf:3 + 2 * nf]
+        L = {"gen_y": gen_y}
+        layer = 0.0
+        for kf, a, b in zip(self.k2_ls, f_y, f_g):
+            layer = layer + (kf * 0.5) * PairLossFn.apply(a, b, 1)
+        L["disc_loss_layer"] = layer
+        L["d_loss_y"], L["d_loss_g"] = self._adv(disc, True), self._adv(gen, False)
+        disc_loss = L["d_loss_y"] * self.weight_dld + L["d_loss_g"]
+        L["gen_l2_loss"] = 0.5 * PairLossFn.apply(ys, gen_y, 1)
+        L["l1_loss"] = PairLossFn.apply(ys, gen_y, 0) / float(gen_y.numel())
+        L["g_loss_d"] = self._adv(gen, True)
+        if self.use_wgan_gp and need_gp:
+            if lerp_factor is None:
+                lerp_factor = torch.rand((xs.shape[0], 1), generator=self.rng)
+            lf = torch.as_tensor(lerp_factor, dtype=torch.float32, device=dev).reshape(-1, 1)
+            # d(penalty)/d(generator) is never used: the discriminator step only updates d_var (:1340-1350)
+            y_gp = (lf * ys + (1.0 - lf) * gen_y.detach()).requires_grad_(True)
+            d_out = self.sess.run([self.d_out], {self.x_disc: xs, self.y_gp: y_gp, self.percentage: percentage})[0]
+            (grads_d,) = torch.autograd.grad(d_out.mean(), y_gp, create_graph=True)
+            norm = torch.sqrt(((grads_d + 1e-4) ** 2).sum(dim=1))
+            L["grad_penalty_d"] = (self.wgan_lambda * (norm - self.wgan_target) ** 2).mean()
+            L["epsilon_penalty_d"] = (disc ** 2).mean()
+            disc_loss = disc_loss + L["epsilon_penalty_d"] * self.wgan_epsilon + L["grad_penalty_d"]
+        L["disc_loss"] = disc_loss
+        L["gen_loss_complete"] = L["g_loss_d"] + L["l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
+        return L
+
+    def disc_step(self, batch_xs, batch_ys, percentage=3.0, lerp_factor=None):
+        L = self.losses(batch_xs, batch_ys, percentage, lerp_factor)
+        grads = torch.autograd.grad(L["disc_loss"], self.opt_d.params, allow_unused=True)
+        self.opt_d.step(grads)
+        return L
+
+    def gen_step(self, batch_xs, batch_ys, percentage=3.0):
+        L = self.losses(batch_xs, batch_ys, percentage, need_gp=False)
+        grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
+        self.opt_g.step(grads)
+        with torch.no_grad():       # MovingAverageOptimizer(…, 0.999): shadow += (1 - decay) * (var - shadow)
+            torch._foreach_lerp_(self.ema, [p.detach() for p in self.opt_g.params], 1.0 - self.ema_decay)
+        return L
+
+    def train_step(self, batch_xs, batch_ys, percentage=3.0, discRuns=1, genRuns=1):
+        for _ in range(discRuns):
+            Ld = self.disc_step(batch_xs, batch_ys, percentage)
+        for _ in range(genRuns):
+            Lg = self.gen_step(batch_xs, batch_ys, percentage)
         return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()

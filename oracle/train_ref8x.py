@@ -1,0 +1,149 @@
+"""CPU restatement of the 8x progressive-growing training graph with float64 PyTorch autograd.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``); parity unpinned (no TF 1.x, no reference
+fixtures for gradients), cross-checked against the numpy generator of ``oracle/nets.py`` at
+percentage = 3 and against finite differences (tests/test_oracle.py).  Follows multipassGAN-8x.py:
+lerp :598, resBlock :606-623, growBlockGen :625-675, growing_gen :677-744 (training wiring with the
+density heads), growBlockDisc :752-780, growing_disc :783-863, losses :1082-1142 (WGAN-GP).
+upsampling_mode 2, firstNNArch 1 or 0, pixelNorm on, batch norm off — the configuration of
+example_run_training.py.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops as O
+from .train_ref import conv2d_same, lrelu
+
+DT = torch.float64
+
+
+def _ws(w, gain):
+    return float(np.float32(gain / np.sqrt(np.prod(w.shape[:-1]))))
+
+
+def conv(p, scope, x, act=None, gain=math.sqrt(2.0)):
+    w = p[scope + "/weight"]
+    y = conv2d_same(x, w * _ws(w, gain), 1) + p[scope + "/bias"].view(1, -1, 1, 1)
+    if act == "relu":
+        return torch.relu(y)
+    if act == "lrelu":
+        return lrelu(y)
+    return y
+
+
+def pixel_norm(x, eps=1e-8):
+    return x * torch.rsqrt((x * x).mean(dim=1, keepdim=True) + eps)
+
+
+def lerp(x, y, t):
+    t = min(max(float(t), 0.0), 1.0)
+    return x + (y - x) * t
+
+
+def up2(x):
+    return x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+
+
+def res_block(p, scope, x, name, k_unused=None, pn=True):
+    a = conv(p, scope + "g_cA_" + name, x, "relu")
+    if pn:
+        a = pixel_norm(a)
+    b = conv(p, scope + "g_cB_" + name, a)
+    s = conv(p, scope + "g_s_" + name, x)
+    r = torch.relu(b + s)
+    return pixel_norm(r) if pn else r
+
+
+def growing_gen(p, x_nhwc_np, percentage, first_nn_arch=True, current_upres=3, pn=True):
+    """x: numpy [N,h,w,C] -> [N,1,H,W] float64 tensor (training wiring: density heads + fade-in)"""
+    x_in = torch.tensor(np.asarray(x_nhwc_np), dtype=DT).permute(0, 3, 1, 2)
+    g = "generator/"
+    x_g = x_in
+    if not first_nn_arch:
+        x_g = res_block(p, g, x_g, "1", pn=pn)
+        x_g = res_block(p, g, x_g, "2", pn=pn)
+    old = conv(p, g + "g_cdensOut1", x_g, None, gain=1)
+    names = ["first", "second", "third", "fourth", "fifth"]
+    for j in range(1, current_upres + 1):
+        up = 2 ** j
+        sc = g + "genBlock%d/" % up
+        h = up2(x_g)
+        n_res = {2: 5, 4: 3, 8: 2}[up] if first_nn_arch else 2
+        for i in range(n_res):
+            h = res_block(p, sc, h, names[i], pn=pn)
+        x_g = h
+        dens = conv(p, sc + "g_cdensOut%d" % up, x_g, None, gain=1)
+        n, hh = x_nhwc_np.shape[0], x_nhwc_np.shape[1]
+        bic = O.resize_bicubic_tf1(np.asarray(x_nhwc_np[..., :1], np.float32), hh * up, hh * up)
+        dens = dens + torch.tensor(bic, dtype=DT).permute(0, 3, 1, 2)
+        old = lerp(up2(old), dens, percentage - (j - 1))
+    return old
+
+
+def grow_block_disc(p, sc, name, x, upres):
+    x1 = conv(p, sc + "%s_cA%d" % (name, upres), x, "lrelu")
+    x2 = conv(p, sc + "%s_cB%d" % (name, upres), x1, "lrelu")
+    return F.avg_pool2d(x2, 2), x1, x2
+
+
+def growing_disc(p, high_nchw, low_density_np, percentage, up_res=8, current_upres=3):
+    """high: [N,1,H,W] tensor; low_density: numpy [N,h,w,1] (channel 0 of the generator input).
+    first_nn_arch wiring: the head reads the pooled x2 of the last block (GAN.layer), the blended x_ only
+    feeds the feature list.  Returns (score [N,1], features)."""
+    d = "spatial-disc/"
+    low = torch.tensor(O.resize_nearest_tf1(np.asarray(low_density_np, np.float32), low_density_np.shape[1] * up_res,
+                                            low_density_np.shape[2] * up_res), dtype=DT).permute(0, 3, 1, 2)
+    inp = torch.cat([low, high_nchw], dim=1)
+    x = conv(p, d + "d_cfromDensity%d" % up_res, inp)
+    feats = [lerp(torch.zeros_like(x), x, percentage - (current_upres - 1))]
+    in_high = inp
+    pooled = None
+    for j in range(current_upres, 0, -1):
+        in_high = F.avg_pool2d(in_high, 2)
+        pooled, x1, x2 = grow_block_disc(p, d + "dBlock%d/" % (2 ** j), "d", x, 2 ** j)
+        old = conv(p, d + "d_cfromDensity%d" % (2 ** (j - 1)), in_high)
+        x = lerp(old, pooled, percentage - (j - 1))
+        feats.append(lerp(torch.zeros_like(x1), x1, percentage - (j - 1)))
+        feats.append(lerp(torch.zeros_like(x2), x2, percentage - (j - 1)))
+    feats.append(lerp(torch.zeros_like(x), x, percentage))
+    flat = pooled.permute(0, 2, 3, 1).reshape(pooled.shape[0], -1)
+    w = p[d + "d_l61/weight"]
+    score = flat @ (w * _ws(w, 1.0)) + p[d + "d_l61/bias"]
+    return score, feats
+
+
+def losses_8x(p, batch_xs, batch_ys, tile_low, channels, percentage=3.0, lerp_factor=None, lambda_l1=1.0, lambda2=0.0,
+              wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True):
+    """WGAN-GP losses of multipassGAN-8x.py:1082-1142 at the final growing stage's tile size"""
+    up = 8
+    th = tile_low * up
+    xs = np.asarray(batch_xs, np.float32).reshape(-1, tile_low, tile_low, channels)
+    y = torch.tensor(np.asarray(batch_ys), dtype=DT).reshape(-1, 1, th, th)
+    gen_y = growing_gen(p, xs, percentage, first_nn_arch)
+    low = xs[..., :1]
+    disc, f_y = growing_disc(p, y, low, percentage)
+    gen, f_g = growing_disc(p, gen_y, low, percentage)
+    L = {"gen_y": gen_y}
+    layer = 0.0
+    for a, b in zip(f_y, f_g):
+        layer = layer + 0.5 * ((a - b) ** 2).sum()
+    L["disc_loss_layer"] = layer
+    L["d_loss_y"], L["d_loss_g"] = (-disc).mean(), gen.mean()
+    disc_loss = L["d_loss_y"] * weight_dld + L["d_loss_g"]
+    L["l1_loss"] = (y - gen_y).abs().mean()
+    L["g_loss_d"] = (-gen).mean()
+    if lerp_factor is not None:
+        lf = torch.tensor(np.asarray(lerp_factor), dtype=DT).reshape(-1, 1, 1, 1)
+        y_gp = (lf * y + (1 - lf) * gen_y.detach()).requires_grad_(True)
+        d_out, _ = growing_disc(p, y_gp, low, percentage)
+        (g,) = torch.autograd.grad(d_out.mean(), y_gp, create_graph=True)
+        norm = torch.sqrt(((g.reshape(g.shape[0], -1) + 1e-4) ** 2).sum(dim=1))
+        L["grad_penalty_d"] = (wgan_lambda * (norm - wgan_target) ** 2).mean()
+        L["epsilon_penalty_d"] = (disc ** 2).mean()
+        disc_loss = disc_loss + L["epsilon_penalty_d"] * wgan_epsilon + L["grad_penalty_d"]
+    L["disc_loss"] = disc_loss
+    L["gen_loss_complete"] = L["g_loss_d"] + L["l1_loss"] * lambda_l1 + L["disc_loss_layer"] * lambda2
+    return L

@@ -1,0 +1,109 @@
+"""8x progressive-growing training: growing_gen with its density heads and
+fade-in, growing_disc, WGAN-GP with the gradient of the gradient through the conv kernels, against the
+float64 autograd restatement (oracle/train_ref8x.py).  Tolerances as in test_train_gpu.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_ref as TR
+from oracle import train_ref8x as TR8
+from oracle.nets import ParamSource
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def make(tile=8, C=6, batch=3, fms=32, seed=9, **kw):
+    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.train import Trainer8x
+    cfg = Cfg8x(tileSizeLow=tile, upRes=8, n_inputChannels=C, start_fms=fms, max_fms=fms)
+    tr = Trainer8x(cfg, device=DEV, seed=seed, **kw)
+    ps = ParamSource(seed=seed)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in tr.graph.variables.items()}
+    with torch.no_grad():
+        for n, t in tr.sess.params.items():
+            t.copy_(torch.as_tensor(params[n], device=DEV))
+    rng = np.random.default_rng(3)
+    xs = rng.random((batch, tile * tile * C)).astype(np.float32)
+    ys = rng.random((batch, (tile * 8) ** 2)).astype(np.float32)
+    lf = rng.random((batch, 1)).astype(np.float32)
+    return tr, TR.to_params(params), xs, ys, lf
+
+
+@pytest.mark.parametrize("percentage", [3.0, 1.4])
+def test_growing_nets_forward(percentage):
+    tr, p, xs, ys, lf = make()
+    L = tr.losses(xs, ys, percentage, lf)
+    Lr = TR8.losses_8x(p, xs, ys, 8, 6, percentage, lf)
+    assert rel(L["gen_y"].detach().cpu().numpy().reshape(3, -1), Lr["gen_y"].detach().numpy().reshape(3, -1)) < 1e-4
+    for k in ("d_loss_y", "d_loss_g", "l1_loss", "g_loss_d", "disc_loss_layer", "epsilon_penalty_d", "grad_penalty_d",
+              "disc_loss", "gen_loss_complete"):
+        a, b = float(L[k].detach()), float(Lr[k].detach())
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-2), (k, a, b)
+
+
+@pytest.mark.parametrize("percentage", [3.0, 2.3])
+def test_wgan_gp_gradients(percentage):
+    """discriminator step (incl. the gradient penalty: second-order through conv / lrelu / avg_pool / lerp) and
+    generator step gradients of every parameter"""
+    tr, p, xs, ys, lf = make()
+    L = tr.losses(xs, ys, percentage, lf)
+    gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+    Lr = TR8.losses_8x(p, xs, ys, 8, 6, percentage, lf)
+    rd = TR.grads(Lr["disc_loss"], p, "d_")
+    rg = TR.grads(Lr["gen_loss_complete"], p, "g_")
+    assert sorted(rd) == tr.opt_d.names and sorted(rg) == tr.opt_g.names
+    worst = 0.0
+    for names, got, want in ((tr.opt_d.names, gd, rd), (tr.opt_g.names, gg, rg)):
+        tot_d = tot_r = 0.0
+        for nme, g in zip(names, got):
+            w = want[nme]
+            gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
+            if np.abs(w).max() == 0.0:
+                assert np.abs(gnp).max() < 1e-7, nme       # heads faded out completely (t = 1)
+                continue
+            r = rel(gnp, w)
+            worst = max(worst, r)
+            assert r < 5e-3, (nme, r)      # d_l61/bias: +1/B and -1/B cancel, the 1e-3 epsilon penalty is left
+            tot_d += float(((gnp - w) ** 2).sum())
+            tot_r += float((w ** 2).sum())
+        assert math.sqrt(tot_d / tot_r) < 3e-4
+    print("worst per-tensor gradient error", worst)
+
+
+def test_train_step_runs_and_moves_both_networks():
+    tr, p, xs, ys, lf = make()
+    before = {n: t.detach().clone() for n, t in tr.sess.params.items()}
+    ema0 = [e.clone() for e in tr.ema]
+    d, g = tr.train_step(xs, ys, 3.0)
+    assert np.isfinite(float(d)) and np.isfinite(float(g))
+    moved_d = sum(int(not torch.equal(tr.sess.params[n].detach(), before[n])) for n in tr.opt_d.names)
+    moved_g = sum(int(not torch.equal(tr.sess.params[n].detach(), before[n])) for n in tr.opt_g.names)
+    assert moved_d >= len(tr.opt_d.names) - 6      # the faded-out d_cfromDensity{4,2,1} convs keep zero gradients
+    assert moved_g >= len(tr.opt_g.names) - 6      # the three faded-out density heads keep zero gradients
+    # shadow = 0.999 shadow + 0.001 var
+    for e0, e1, pr in zip(ema0, tr.ema, tr.opt_g.params):
+        assert torch.allclose(e1, e0 + 0.001 * (pr.detach() - e0), atol=1e-7)
+    l1 = [float(tr.gen_step(xs, ys, 3.0)["l1_loss"].detach()) for _ in range(8)]
+    assert l1[-1] < l1[0]
+
+
+def test_lsgan_variant_losses():
+    tr, p, xs, ys, lf = make(use_wgan_gp=False, use_LSGAN=True)
+    L = tr.losses(xs, ys, 3.0)
+    Lr = TR8.losses_8x(p, xs, ys, 8, 6, 3.0, None)
+    gen_y = Lr["gen_y"]
+    low = xs.reshape(-1, 8, 8, 6)[..., :1]
+    disc, _ = TR8.growing_disc(p, torch.tensor(ys, dtype=torch.float64).reshape(-1, 1, 64, 64), low, 3.0)
+    gen, _ = TR8.growing_disc(p, gen_y, low, 3.0)
+    want = 0.5 * ((disc - 1.0) ** 2).mean() + 0.5 * (gen ** 2).mean()
+    assert abs(float(L["disc_loss"].detach()) - float(want)) < 2e-4 * max(abs(float(want)), 1e-2)
