@@ -5,7 +5,13 @@ G + D forward/backward + both Adam updates on a batch of 16 density+velocity til
 256^2 variant that loads the matrix cores).  Same JSON contract as bench.py; the driver's headline
 run stays bench.py.
 
-  python bench_train.py [--tile 16] [--batch 16] [--steps 20] [--warmup 3] [--eager]
+  python bench_train.py [--workload c3|c5] [--tile 16] [--batch 16] [--steps 20] [--warmup 3] [--eager]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_train.py --gpus N ...
+
+`--workload c5` is one stage-3 iteration of the 8x progressive-growing training (BASELINE configs[4]):
+growing_gen (firstNNArch, startFms 256, 6 input channels) + growing_disc, WGAN-GP, tileSize 16 -> 128^2,
+batch 16 per GPU.  With N > 1 every rank trains on its own batch and the flat gradient bucket of each
+optimiser is averaged with one RCCL all-reduce before the Adam kernel (weak scaling).
 """
 import argparse
 import json
@@ -36,26 +42,27 @@ def fwd_flops_per_tile(tile_high, c):
     return g, d
 
 
-def wgrad_roofline(device, tile_high, batch, iters=10):
-    """the matrix-core weight gradient of resBlock 1's 5x5 128->128 conv on one batch"""
+def wgrad_roofline(device, tile_high, batch, iters=10, k=5, c=128):
+    """the matrix-core weight gradient of the widest conv of the step on one batch (4x: resBlock 1's 5x5
+    128->128; 8x net1: a 3x3 64->64 conv of the 4x level)"""
     from mpgan_amd import train_ops
     g = torch.Generator(device=device).manual_seed(1)
-    x = torch.randn((batch, tile_high, tile_high, 128), device=device, generator=g).relu_()
-    dy = torch.randn((batch, tile_high, tile_high, 128), device=device, generator=g) * 1e-4
+    x = torch.randn((batch, tile_high, tile_high, c), device=device, generator=g).relu_()
+    dy = torch.randn((batch, tile_high, tile_high, c), device=device, generator=g) * 1e-4
     for _ in range(2):
-        train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3)
+        train_ops.conv2d_wgrad_mfma(x, dy, k, k, 0.025, 3)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
     e0.record()
     for _ in range(iters):
-        train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3)
+        train_ops.conv2d_wgrad_mfma(x, dy, k, k, 0.025, 3)
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * 25 * 128 * 128 * tile_high * tile_high * batch
+    flops = 2.0 * k * k * c * c * tile_high * tile_high * batch
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_mfma 5x5 128->128 (absmax + P16 rewrite + wgrad_mfma_kernel<5,2,3> x2), "
-                                       "%d tiles of %d^2" % (batch, tile_high),
+    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_mfma %dx%d %d->%d (absmax + P16 rewrite + wgrad_mfma_kernel), "
+                                       "%d tiles of %d^2" % (k, k, c, c, batch, tile_high),
             "achieved": round(ach, 2), "peak": DENSE_F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / DENSE_F16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_products_per_mac": "3 fp16"}
@@ -93,7 +100,8 @@ def cpu_baseline(tile, batch, c, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--tile", type=int, default=16, help="low-res tile edge (high-res = 4x)")
+    ap.add_argument("--workload", default="c3", choices=("c3", "c5"))
+    ap.add_argument("--tile", type=int, default=16, help="low-res tile edge (high-res = 4x / 8x)")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
@@ -101,47 +109,93 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    if args.gpus != 1:
-        raise SystemExit("bench_train.py measures one GPU (data-parallel training is a later row)")
     from mpgan_amd import _lib
-    from mpgan_amd.train import Trainer4x
+    from mpgan_amd import dist as mdist
+    from mpgan_amd.train import Trainer4x, Trainer8x
     _lib.load()
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: the training step has no CPU fallback")
-    dev = torch.device("cuda:0")
-    tr = Trainer4x(tileSizeLow=args.tile, upRes=4, n_inputChannels=args.channels, batch_norm=True, device="cuda:0")
-    rng = np.random.default_rng(0)
+    comm, dev = mdist.init_from_env()
+    rank = comm.rank if comm else 0
+    world = comm.world if comm else 1
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d (launch with torch.distributed.run)" % (args.gpus, world))
+    rng = np.random.default_rng(rank)
+    if args.workload == "c5":
+        out = bench_c5(args, comm, dev, rank, world, rng)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+    tr = Trainer4x(tileSizeLow=args.tile, upRes=4, n_inputChannels=args.channels, batch_norm=True, device=str(dev), comm=comm)
     xs = torch.as_tensor(rng.random((args.batch, args.tile ** 2 * args.channels)).astype(np.float32), device=dev)
     ys = torch.as_tensor(rng.random((args.batch, (args.tile * 4) ** 2)).astype(np.float32), device=dev)
-    step = tr.train_step if args.eager else tr.train_step_graphed
-    for _ in range(max(args.warmup, 1)):
-        step(xs, ys)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(args.steps):
-        d, g = step(xs, ys)
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / args.steps
+    step = tr.train_step if (args.eager or world > 1) else tr.train_step_graphed
+    dt, (d, g) = timed(step, (xs, ys), args, comm, dev)
     th = args.tile * 4
     gf, df = fwd_flops_per_tile(th, args.channels)
     # D-step: G fwd, D fwd x2, D bwd x2 (dgrad + wgrad = 2x fwd); G-step: G fwd, D fwd x2, D(fake) dgrad, G bwd (2x)
     flops = args.batch * ((gf + 2 * df + 2 * 2 * df) + (gf + 2 * df + df + 2 * gf))
     out = {
-        "metric": "training iterations/s, 4x GAN step (G+D fwd/bwd + Adam), %d tiles of %d^2, %d channels" % (args.batch, th, args.channels),
-        "value": round(1.0 / dt, 3), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "metric": "training iterations/s, 4x GAN step (G+D fwd/bwd + Adam), %d tiles of %d^2 per GPU, %d channels" % (args.batch, th, args.channels),
+        "value": round(1.0 / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16x3 (fp16 hi/lo split, three MFMA products, fp32 accumulate)", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: 4x training step, tileSize %d -> %d^2, batch %d, density+velocity, "
                                "batchNorm on, spatial discriminator, discRuns=genRuns=1" % (args.tile, th, args.batch),
-                   "launch": "eager" if args.eager else "hipGraph replay", "tiles_per_s": round(args.batch / dt, 1),
+                   "launch": "eager" if (args.eager or world > 1) else "hipGraph replay",
+                   "tiles_per_s": round(world * args.batch / dt, 1), "parallelism": "dp%d" % world,
                    "algorithmic_tflop_per_iteration": round(flops / 1e12, 3),
                    "algorithmic_tflops": round(flops / dt / 1e12, 1),
                    "disc_loss": float(d), "gen_loss_complete": float(g)},
         "roofline": wgrad_roofline(dev, th, args.batch),
     }
-    if not args.no_cpu_baseline:
+    if rank != 0:
+        return
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.tile, args.batch, args.channels, 5)
     print(json.dumps(out))
+
+
+def timed(step, batch, args, comm, dev):
+    """W warm-up steps, then K steps bracketed by barrier + synchronize; the maximum over ranks"""
+    for _ in range(max(args.warmup, 1)):
+        res = step(*batch)
+    torch.cuda.synchronize(dev)
+    if comm:
+        comm.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        res = step(*batch)
+    torch.cuda.synchronize(dev)
+    if comm:
+        comm.barrier()
+    dt = (time.time() - t0) / args.steps
+    if comm:
+        dt = comm.max_float(dt, dev)
+    return dt, res
+
+
+def bench_c5(args, comm, dev, rank, world, rng):
+    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.train import Trainer8x
+    cfg = Cfg8x(tileSizeLow=args.tile, upRes=8, n_inputChannels=6, start_fms=256, max_fms=256)
+    tr = Trainer8x(cfg, device=str(dev), comm=comm)
+    xs = torch.as_tensor(rng.random((args.batch, cfg.n_input)).astype(np.float32), device=dev)
+    ys = torch.as_tensor(rng.random((args.batch, cfg.n_output)).astype(np.float32), device=dev)
+    dt, (d, g) = timed(lambda a, b: tr.train_step(a, b, 3.0), (xs, ys), args, comm, dev)
+    th = cfg.tileSizeHigh
+    return {
+        "metric": "training iterations/s, 8x progressive-growing stage 3 (growing_gen + growing_disc, WGAN-GP, Adam), "
+                  "%d tiles of %d^2 per GPU" % (args.batch, th),
+        "value": round(1.0 / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16x3 (fp16 hi/lo split, three MFMA products, fp32 accumulate)", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] per GPU: multipassGAN-8x.py final stage (percentage 3.0), tileSize %d -> %d^2, "
+                               "batch %d, firstNNArch, startFms 256, 6 input channels, WGAN-GP" % (args.tile, th, args.batch),
+                   "parallelism": "dp%d" % world, "tiles_per_s": round(world * args.batch / dt, 1),
+                   "disc_loss": float(d), "gen_loss_complete": float(g)},
+        "roofline": wgrad_roofline(dev, th // 2, args.batch, k=3, c=64) if rank == 0 else None,
+    }
 
 
 if __name__ == "__main__":

@@ -626,7 +626,7 @@ class Trainer4x(object):
 
     def __init__(self, tileSizeLow=16, upRes=4, n_inputChannels=4, batch_norm=True, upsampling_mode=2, device="cuda:0",
                  learning_rate=2e-4, beta1=0.5, lambda_l1=1.0, lambda2=0.0, lambda2_l=(1.0, 1.0, 1.0, 1.0),
-                 weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777):
+                 weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777, comm=None):
         from . import nets
         from .session import VariableStore
         self.tileSizeLow, self.upRes, self.C = tileSizeLow, upRes, n_inputChannels
@@ -651,8 +651,8 @@ class Trainer4x(object):
                                  device=device)
         self.g_var = self.sess.trainable("g_")
         self.d_var = self.sess.trainable("d_")
-        self.opt_d = AdamTF(self.d_var, learning_rate, beta1)
-        self.opt_g = AdamTF(self.g_var, learning_rate, beta1)
+        self.opt_d = AdamTF(self.d_var, learning_rate, beta1, comm=comm)
+        self.opt_g = AdamTF(self.g_var, learning_rate, beta1, comm=comm)
 
     def losses(self, batch_xs, batch_ys):
         """-> dict of the loss tensors of multipassGAN-4x.py:744-768 (one forward of G, D(real), D(fake))"""

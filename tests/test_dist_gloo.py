@@ -83,6 +83,16 @@ def _worker(rank, world, port, path):
     assert (comm.rank, comm.world) == (rank, world)
     outs = _pipelines(comm)
     assert comm.max_float(float(rank), torch.device("cpu")) == world - 1
+    # data-parallel training: the flat gradient bucket of an optimiser is averaged over the ranks before
+    # the Adam kernel (train.AdamTF.step); here with the kernel stubbed out, on CPU buffers
+    from mpgan_amd import train as mtrain
+    params = {"a/weight": torch.zeros(3, 2, requires_grad=True), "b/bias": torch.zeros(4, requires_grad=True)}
+    opt = mtrain.AdamTF(params, comm=comm)
+    seen = {}
+    mtrain.train_ops.adam_step = lambda flat, grad, m, v, lr_t, b1, b2, eps: seen.update(grad=grad.clone(), lr=float(lr_t))
+    opt.step([torch.full((3, 2), float(rank + 1)), None if rank == 0 else torch.full((4,), 2.0)])
+    outs["dp_grad"] = seen["grad"].numpy()
+    outs["dp_lr_t"] = np.float64(seen["lr"])
     comm.barrier()
     np.savez(path % rank, **outs)
     dist.destroy_process_group()
@@ -98,6 +108,9 @@ def test_sharded_pipelines_match_single_rank(tmp_path):
         got = np.load(path % r)
         for k, v in ref.items():
             assert np.array_equal(got[k], v), (r, k)
+        # mean over ranks of (1, 2) and of (unconnected -> 0, 2); Adam step size of t = 1
+        assert np.allclose(got["dp_grad"], [1.5] * 6 + [1.0] * 4)
+        assert abs(float(got["dp_lr_t"]) - 2e-4 * np.sqrt(1 - 0.999) / (1 - 0.5)) < 1e-12
 
 
 def test_slice_range_and_errors(mpg):
