@@ -646,6 +646,129 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int kh, int kw,
     if (NPL == 2) out[stage * plane * NPL + plane + off] = (_Float16)(v - (float)hi);
 }
 
+// fp32 table [tap][ci 8][co 8] of a small layer (zero padded), scaled like the MFMA pack
+__global__ void pack_small_kernel(const float* __restrict__ w, int taps, int cin_total, int c_off, int cin, int cout,
+                                  float wscale, const float* __restrict__ cscale, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= taps * 64) return;
+    const int co = idx & 7, ci = (idx >> 3) & 7, tap = idx >> 6;
+    float v = 0.f;
+    if (ci < cin && co < cout) {
+        v = w[((size_t)tap * cin_total + c_off + ci) * cout + co] * wscale;
+        if (cscale != nullptr) v *= cscale[co];
+    }
+    out[idx] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_small_kernel: fused convolution for layers with <= 8 input and <= 8 output channels per
+// segment.  One thread per output pixel holds the 8 output channels; every tap is one 16-byte
+// read per plane of the single G8 channel group (hi + lo -> fp32), the weights are wave-uniform
+// scalar loads.  HBM / L1 bound, fp32 arithmetic on fp32-grade activations.
+// ---------------------------------------------------------------------------------------------
+struct SmallSeg {
+    const char* x;
+    const float* w;       // [tap][8][8]
+    int cg_total, g_off, kh, kw, up, pt, pl, hs, ws, cin;
+};
+
+struct SmallArgs {
+    int n, h, w, cout, nseg, f8c_in;
+    SmallSeg seg[MPG_MAX_SEG];
+    const float* bias;
+    int act;
+    float leak;
+    float* y;
+    char* y_g8;
+    char* y_g8c;
+};
+
+__device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, int f8c, float (&v)[8]) {
+    const half8 hi = *reinterpret_cast<const half8*>(src);
+    if (!f8c) {
+        const half8 lo = *reinterpret_cast<const half8*>(src + plane_bytes);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
+    } else {
+        // plane 1 of the F16F8 flavour: bytes 8..15 hold fp8((v - fp16(v)) * 2^SA_LO)
+        const int2 lo = *reinterpret_cast<const int2*>(src + plane_bytes + 8);
+        const float sc = 1.f / (float)(1 << SA_LO);
+        v[0] = (float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 0) * sc;
+        v[1] = (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 1) * sc;
+        v[2] = (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 2) * sc;
+        v[3] = (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 3) * sc;
+        v[4] = (float)hi[4] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 0) * sc;
+        v[5] = (float)hi[5] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 1) * sc;
+        v[6] = (float)hi[6] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 2) * sc;
+        v[7] = (float)hi[7] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 3) * sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)a.n * a.h * a.w;
+    if (idx >= total) return;
+    const int x = idx % a.w;
+    const size_t t = idx / a.w;
+    const int y = t % a.h;
+    const int b = t / a.h;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (a.bias != nullptr && j < a.cout) ? a.bias[j] : 0.f;
+    for (int s = 0; s < a.nseg; ++s) {
+        const SmallSeg& g = a.seg[s];
+        const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
+        const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            const int yy = y - g.pt + ky;
+            if (yy < 0 || yy >= a.h) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int xx = x - g.pl + kx;
+                if (xx < 0 || xx >= a.w) continue;
+                float v[8];
+                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
+                const float* wt = g.w + (ky * g.kw + kx) * 64;
+#pragma unroll
+                for (int ci = 0; ci < 8; ++ci) {
+                    if (ci < g.cin) {
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v[ci], wt[ci * 8 + co], acc[co]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = j < a.cout ? mpg::apply_act(acc[j], a.act, a.leak) : 0.f;
+    if (a.y != nullptr) {
+        float* dst = a.y + idx * a.cout;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < a.cout) dst[j] = acc[j];
+    }
+    const size_t plane_px = (size_t)a.h * a.w;
+    const size_t pix = (size_t)y * a.w + x;
+    if (a.y_g8 != nullptr) {
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (_Float16)acc[j];
+            lo[j] = (_Float16)(acc[j] - (float)hi[j]);
+        }
+        char* dst = a.y_g8 + ((size_t)b * 2 * plane_px + pix) * 16;
+        *reinterpret_cast<half8*>(dst) = hi;
+        *reinterpret_cast<half8*>(dst + plane_px * 16) = lo;
+    }
+    if (a.y_g8c != nullptr) {
+        half8 hi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hi[j] = (_Float16)acc[j];
+        char* dst = a.y_g8c + ((size_t)b * 2 * plane_px + pix) * 16;
+        *reinterpret_cast<half8*>(dst) = hi;
+        *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(acc);
+    }
+}
+
 // fp32 NHWC -> G8
 __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off, int cin,
                                  int f8c, _Float16* __restrict__ out) {
@@ -823,7 +946,19 @@ extern "C" int mpg_g8_to_f32(mpg_stream_t stream, const void* g8, int n, int h, 
     MPG_LAUNCH_CHECK("g8_to_f32_kernel");
 }
 
+// Layers with at most 8 input and 8 output channels (the first and last residual blocks of gen_resnet:
+// 1->2->8 and 8->2->1) are not matrix work: they run on conv_small_kernel, which reads a plain fp32
+// table [tap][ci 8][co 8] appended to the packed weights.
+static inline bool small_layer(int cin, int cout) { return cin <= 8 && cout <= 8; }
+static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec);
+
 extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec) {
+    const size_t base = pack_base_bytes(kh, kw, cin, cout, prec);
+    if (base == 0) return 0;
+    return base + (small_layer(cin, cout) ? (size_t)kh * kw * 64 * sizeof(float) : 0);
+}
+
+static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec) {
     if (kh < 1 || kw < 1 || kh > 7 || kw > 7 || cin < 1 || cout < 1 || cout > 128) return 0;
     const int nt = (cout + 31) / 32;
     if (prec == MPG_PREC_F16F8) {
@@ -858,6 +993,10 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
         hipLaunchKernelGGL(pack_weights_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ss.nchunks, ss.sc,
                            ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), (char*)out);
+        if (small_layer(cin, cout))
+            hipLaunchKernelGGL(pack_small_kernel, dim3((kh * kw * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                               kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
+                               (float*)((char*)out + pack_base_bytes(kh, kw, cin, cout, prec)));
         MPG_LAUNCH_CHECK("pack_weights_f8_kernel");
     }
     const Shape ps = pipe_shape(nt, prec);
@@ -868,6 +1007,10 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hwio, kh, kw,
                        w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ps.ks, npl, ss.cgc, ss.nchunks, ss.sc,
                        (_Float16*)out);
+    if (small_layer(cin, cout))
+        hipLaunchKernelGGL(pack_small_kernel, dim3((kh * kw * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio,
+                           kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
+                           (float*)((char*)out + pack_base_bytes(kh, kw, cin, cout, prec)));
     MPG_LAUNCH_CHECK("pack_weights_kernel");
 }
 
@@ -880,6 +1023,37 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3 || d->prec == MPG_PREC_F16F8,
                 "mpg_conv2d_fused: bad prec %d", d->prec);
     MPG_REQUIRE(d->act >= MPG_ACT_NONE && d->act <= MPG_ACT_TANH, "mpg_conv2d_fused: bad act %d", d->act);
+    {   // small-channel layers: conv_small_kernel
+        bool small = d->cout <= 8 && !d->pixel_norm && d->post_add == nullptr && d->reserved == 0;
+        for (int s = 0; s < d->nseg && small; ++s) small = d->seg[s].cin <= 8;
+        if (small) {
+            SmallArgs sa;
+            sa.n = d->n; sa.h = d->h; sa.w = d->w; sa.cout = d->cout; sa.nseg = d->nseg;
+            sa.f8c_in = d->prec == MPG_PREC_F16F8 ? 1 : 0;
+            for (int s = 0; s < d->nseg; ++s) {
+                const mpg_conv_seg& g = d->seg[s];
+                MPG_REQUIRE(g.x && g.wpack, "mpg_conv2d_fused: segment %d null pointer", s);
+                MPG_REQUIRE(g.kh >= 1 && g.kh <= 7 && g.kw >= 1 && g.kw <= 7, "mpg_conv2d_fused: segment %d kernel %dx%d", s, g.kh, g.kw);
+                MPG_REQUIRE(g.cin >= 1 && g.g_off >= 0 && g.g_off < g.cgroups, "mpg_conv2d_fused: segment %d channel-group range", s);
+                MPG_REQUIRE(g.up_log2 >= 0 && g.up_log2 <= 4 && (d->h % (1 << g.up_log2)) == 0 && (d->w % (1 << g.up_log2)) == 0,
+                            "mpg_conv2d_fused: segment %d upsample %d", s, g.up_log2);
+                MPG_REQUIRE((((uintptr_t)g.x) & 15) == 0 && (((uintptr_t)g.wpack) & 15) == 0, "mpg_conv2d_fused: segment %d misaligned", s);
+                SmallSeg& o = sa.seg[s];
+                o.x = (const char*)g.x;
+                o.w = (const float*)((const char*)g.wpack + pack_base_bytes(g.kh, g.kw, g.cin, d->cout, d->prec));
+                o.cg_total = g.cgroups; o.g_off = g.g_off; o.kh = g.kh; o.kw = g.kw; o.up = g.up_log2;
+                o.pt = g.pad_hi ? g.kh / 2 : (g.kh - 1) / 2; o.pl = g.pad_hi ? g.kw / 2 : (g.kw - 1) / 2;
+                o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2; o.cin = g.cin;
+            }
+            for (int s = d->nseg; s < MPG_MAX_SEG; ++s) sa.seg[s] = sa.seg[0];
+            sa.bias = d->bias; sa.act = d->act; sa.leak = d->leak;
+            sa.y = d->y; sa.y_g8 = (char*)d->y_g8; sa.y_g8c = (char*)d->y_g8c;
+            MPG_REQUIRE((((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0, "mpg_conv2d_fused: misaligned output");
+            const size_t total = (size_t)d->n * d->h * d->w;
+            hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sa);
+            MPG_LAUNCH_CHECK("conv_small_kernel");
+        }
+    }
     const int nt = (d->cout + 31) / 32;
     const bool f8 = d->prec == MPG_PREC_F16F8;
     if (f8 && !f8_supported(nt)) {

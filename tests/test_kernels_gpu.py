@@ -133,7 +133,10 @@ def test_conv2d_fused_f16f8(gpu_ops, case):
     # F16X1 on the same data is clearly worse: the corrections do their job
     y1 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(x), gpu_ops.pack_conv_weights(_t(wt), wscale=ws, prec=1))], (h, w),
                               bias=_t(b), act=act, pixel_norm=pn)
-    assert err < 0.5 * rel_l2(y1.cpu().numpy(), ref)
+    if cin > 8 or cout > 8:     # small layers run in fp32 on conv_small_kernel whatever the precision flag says
+        assert err < 0.5 * rel_l2(y1.cpu().numpy(), ref)
+    else:
+        assert rel_l2(y1.cpu().numpy(), ref) < 1e-5
 
 
 def test_f16f8_chain_and_flavour_check(gpu_ops, mpg):
