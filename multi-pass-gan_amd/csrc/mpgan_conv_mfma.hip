@@ -704,50 +704,73 @@ __device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, in
     }
 }
 
+// block = 32 x 8 output pixels.  Per segment the halo tile is converted to fp32 ONCE into LDS ([pixel][8
+// channels], zero outside the image), then every thread walks its taps with two ds_read_b128 and
+// cin x COUT FMAs whose weights are wave-uniform scalar loads.
+constexpr int SM_TW = 32, SM_TH = 8;
+
+template <int COUT>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)a.n * a.h * a.w;
-    if (idx >= total) return;
-    const int x = idx % a.w;
-    const size_t t = idx / a.w;
-    const int y = t % a.h;
-    const int b = t / a.h;
-    float acc[8];
+    __shared__ __attribute__((aligned(16))) float tile[(SM_TH + 6) * (SM_TW + 6) * 8];
+    const int tid = threadIdx.x;
+    const int tx = tid % SM_TW, ty = tid / SM_TW;
+    const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
+    const int x = x0 + tx, y = y0 + ty;
+    float acc[8];          // COUT live accumulators (cout rounded up to 1, 2, 4, 8); the rest stays zero
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = (a.bias != nullptr && j < a.cout) ? a.bias[j] : 0.f;
     for (int s = 0; s < a.nseg; ++s) {
         const SmallSeg& g = a.seg[s];
         const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
         const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
-        for (int ky = 0; ky < g.kh; ++ky) {
-            const int yy = y - g.pt + ky;
-            if (yy < 0 || yy >= a.h) continue;
-            for (int kx = 0; kx < g.kw; ++kx) {
-                const int xx = x - g.pl + kx;
-                if (xx < 0 || xx >= a.w) continue;
-                float v[8];
+        const int tw = SM_TW + g.kw - 1, th = SM_TH + g.kh - 1;
+        if (s > 0) __syncthreads();
+        for (int p = tid; p < tw * th; p += 256) {
+            const int hy = p / tw, hx = p - hy * tw;
+            const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
+            float v[8];
+            if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
                 g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            float4* dst = reinterpret_cast<float4*>(tile + p * 8);
+            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
+            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        __syncthreads();
+        for (int ky = 0; ky < g.kh; ++ky) {
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const float4* src = reinterpret_cast<const float4*>(tile + ((ty + ky) * tw + tx + kx) * 8);
+                const float4 lo4 = src[0];
                 const float* wt = g.w + (ky * g.kw + kx) * 64;
+                float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, 0.f, 0.f, 0.f, 0.f};
+                if (g.cin > 4) {
+                    const float4 hi4 = src[1];
+                    v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+                }
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
                     if (ci < g.cin) {
 #pragma unroll
-                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v[ci], wt[ci * 8 + co], acc[co]);
+                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wt[ci * 8 + co], acc[co]);
                     }
                 }
             }
         }
     }
+    if (x >= a.w || y >= a.h) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = j < a.cout ? mpg::apply_act(acc[j], a.act, a.leak) : 0.f;
+    const size_t plane_px = (size_t)a.h * a.w;
+    const size_t pix = (size_t)y * a.w + x;
     if (a.y != nullptr) {
-        float* dst = a.y + idx * a.cout;
+        float* dst = a.y + ((size_t)b * plane_px + pix) * a.cout;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             if (j < a.cout) dst[j] = acc[j];
     }
-    const size_t plane_px = (size_t)a.h * a.w;
-    const size_t pix = (size_t)y * a.w + x;
     if (a.y_g8 != nullptr) {
         half8 hi, lo;
 #pragma unroll
@@ -1050,7 +1073,12 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
             sa.y = d->y; sa.y_g8 = (char*)d->y_g8; sa.y_g8c = (char*)d->y_g8c;
             MPG_REQUIRE((((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0, "mpg_conv2d_fused: misaligned output");
             const size_t total = (size_t)d->n * d->h * d->w;
-            hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sa);
+            (void)total;
+            const dim3 sg((unsigned)((d->w + SM_TW - 1) / SM_TW), (unsigned)((d->h + SM_TH - 1) / SM_TH), (unsigned)d->n);
+            if (d->cout == 1) hipLaunchKernelGGL(conv_small_kernel<1>, sg, dim3(256), 0, (hipStream_t)stream, sa);
+            else if (d->cout == 2) hipLaunchKernelGGL(conv_small_kernel<2>, sg, dim3(256), 0, (hipStream_t)stream, sa);
+            else if (d->cout <= 4) hipLaunchKernelGGL(conv_small_kernel<4>, sg, dim3(256), 0, (hipStream_t)stream, sa);
+            else hipLaunchKernelGGL(conv_small_kernel<8>, sg, dim3(256), 0, (hipStream_t)stream, sa);
             MPG_LAUNCH_CHECK("conv_small_kernel");
         }
     }
