@@ -13,6 +13,17 @@ import torch
 import torch.distributed as dist
 
 
+class _Gathered(object):
+    def __init__(self, full, work, keep=None):
+        self.full, self.work, self.keep = full, work, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = self.keep = None
+        return self.full
+
+
 class Comm(object):
     def __init__(self, group=None):
         self.group = group
@@ -30,6 +41,20 @@ class Comm(object):
         full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
         return full
+
+    def all_gather_slabs_start(self, local, total):
+        """non-blocking all_gather_slabs: returns a handle whose wait() makes the current stream (RCCL) or
+        the host (gloo) wait and returns the full tensor, so the exchange overlaps the work issued in between"""
+        if self.world == 1:
+            return _Gathered(local, None)
+        per = total // self.world
+        if local.shape[0] != per:
+            raise ValueError("slab has %d slices, expected %d" % (local.shape[0], per))
+        local = local.contiguous()
+        full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        work = dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group,
+                               async_op=True)
+        return _Gathered(full, work, keep=local)
 
     def all_reduce_mean(self, flat):
         """data-parallel training: average one flat gradient buffer (one bucket per optimiser) in place"""

@@ -106,23 +106,43 @@ def _run_pass(gen, xs, ys, lo, hi, batch, out=None):
 # ----------------------------------------------------------------------------
 # 4x: two networks chained (example_run_output.py:4-8)
 # ----------------------------------------------------------------------------
-def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
-    """low: device [z,y,x,C].  Returns (final [z,y,x], pass-1 volume [z,y,x]), both with the
-    <5e-4 cutoff of the files the reference writes between and after the passes."""
-    comm = comm or LocalComm()
-    sim, nch = low.shape[0], low.shape[3]
-    s = sim * up_res
+class _Now(object):
+    """an exchange that already happened (single rank)"""
+
+    def __init__(self, full):
+        self.full = full
+
+    def wait(self):
+        return self.full
+
+
+def _start_gather(comm, local, total):
+    if hasattr(comm, "all_gather_slabs_start"):
+        return comm.all_gather_slabs_start(local, total)
+    return _Now(comm.all_gather_slabs(local, total))
+
+
+def _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale):
+    """pass 1 of one volume: upsamplingMode 2 -- zoom z, slices along z (4x.py:1103,1126-1133); the
+    all-gather of the slabs is started, not awaited"""
+    nch = low.shape[3]
+    s = low.shape[0] * up_res
     low1 = low
     if nch > 1 and vel_scale != 1.0:
         low1 = low.clone()
         low1[..., 1:4] *= vel_scale                                  # 4x.py:283, first run: vx,vy,vz
-    # pass 1: upsamplingMode 2 -- zoom z, slices along z (4x.py:1103,1126-1133)
     xs = backend.axis_zoom_linear(low1, 0, up_res)                   # [s, sim, sim, C]
     lo, hi = slice_range(s, comm)
     out1 = _run_pass(gen1, xs, None, lo, hi, batch)                  # [hi-lo, s, s] = (z, y, x)
     out1 = backend.cutoff(out1, CUTOFF)                              # 4x.py:1156-1157
-    v1 = comm.all_gather_slabs(out1, s)                              # [z, y, x]
-    # pass 2: upsamplingMode 1 -- slices along x of (z, y) planes (4x.py:1113-1119)
+    return _start_gather(comm, out1, s)
+
+
+def _pass2_4x(gen2, low, v1, up_res, batch, comm, backend, vel_scale):
+    """pass 2: upsamplingMode 1 -- slices along x of (z, y) planes (4x.py:1113-1119)"""
+    nch = low.shape[3]
+    s = low.shape[0] * up_res
+    lo, hi = slice_range(s, comm)
     if nch > 1:
         vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
         if vel_scale != 1.0:
@@ -135,9 +155,41 @@ def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_
     else:
         xin = backend.volume_transpose(v1, (2, 0, 1)).reshape(s, s, s, 1)
     out2 = _run_pass(gen2, xin, None, lo, hi, batch)                 # [x-range][z][y]
-    full2 = comm.all_gather_slabs(out2, s)                           # [x, z, y]
+    return _start_gather(comm, out2, s)
+
+
+def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
+    """low: device [z,y,x,C].  Returns (final [z,y,x], pass-1 volume [z,y,x]), both with the
+    <5e-4 cutoff of the files the reference writes between and after the passes."""
+    comm = comm or LocalComm()
+    v1 = _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale).wait()         # [z, y, x]
+    full2 = _pass2_4x(gen2, low, v1, up_res, batch, comm, backend, vel_scale).wait()  # [x, z, y]
     final = backend.volume_transpose(full2, (1, 2, 0), cutoff=CUTOFF)   # 4x.py:1142,1156
     return final, v1
+
+
+def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
+    """The same two passes over a list of independent volumes, software-pipelined by one volume so that the
+    slab exchange of volume i (RCCL all-gather on its own stream) runs under pass 1 of volume i+1 and
+    pass 2 of volume i-1.  Same results as calling two_pass_4x per volume.  Returns the final volumes."""
+    comm = comm or LocalComm()
+    n = len(lows)
+    g1, v1s, g2 = [None] * n, [None] * n, [None] * n
+    finals = [None] * n
+    for i in range(n + 2):
+        if i < n:
+            g1[i] = _pass1_4x(gen1, lows[i], up_res, batch, comm, backend, vel_scale)
+        j = i - 1
+        if 0 <= j < n:
+            v1s[j] = g1[j].wait()
+            g1[j] = None
+            g2[j] = _pass2_4x(gen2, lows[j], v1s[j], up_res, batch, comm, backend, vel_scale)
+            v1s[j] = None
+        k = i - 2
+        if 0 <= k < n:
+            finals[k] = backend.volume_transpose(g2[k].wait(), (1, 2, 0), cutoff=CUTOFF)
+            g2[k] = None
+    return finals
 
 
 # ----------------------------------------------------------------------------

@@ -61,6 +61,11 @@ def _pipelines(comm):
         final, v1 = MP.two_pass_4x(g1, g2, low, 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5)
         outs["4x_c%d" % nch] = final.numpy()
         outs["4x_c%d_v1" % nch] = v1.numpy()
+        # the pipelined batch form (exchange of volume i under the passes of its neighbours) is the same arithmetic
+        low_b = torch.as_tensor(synthetic_volume(4, nch, 5))
+        fb = MP.two_pass_4x_batch(g1, g2, [low, low_b, low], 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5)
+        assert np.array_equal(fb[0].numpy(), final.numpy()) and np.array_equal(fb[2].numpy(), final.numpy())
+        outs["4x_c%d_batch1" % nch] = fb[1].numpy()
     low = torch.as_tensor(synthetic_volume(2, 4, 4))
     cfgs = [dict(up_res=8, first_gen=True, filter_size=3, start_fms=32, max_fms=32, first_nn_arch=True, add_adj=True),
             dict(up_res=8, first_gen=False, filter_size=3, start_fms=32, max_fms=32),
