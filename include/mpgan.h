@@ -240,6 +240,14 @@ int mpg_resize_nearest_bwd(mpg_stream_t stream, const float* dy, int n, int oh, 
 int mpg_avg_pool2_bwd(mpg_stream_t stream, const float* dy, int n, int h, int w, int c, float* dx);
 /* lerp(x, y, t) = x + (y - x) * t with t already clipped to [0,1] (multipassGAN-8x.py:598-599); x NULL = zeros */
 int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, size_t n, float t, float* out);
+/* tensorResample (multipassGAN-4x.py:398-441; 8x.py:547-595), 2D: out[b,i,j,:] = bilinear look-up of
+ * value[b] at pos[b,i,j] = (y, x) in cell-centred coordinates, indices clamped to the grid when `clamp`
+ * (script default); the advection step of the temporal discriminator inputs.  _bwd: gradient with
+ * respect to value (dvalue is overwritten). */
+int mpg_tensor_resample(mpg_stream_t stream, const float* value, const float* pos, int n, int h, int w, int c,
+                        int clamp, float* out);
+int mpg_tensor_resample_bwd(mpg_stream_t stream, const float* dy, const float* pos, int n, int h, int w, int c,
+                            int clamp, float* dvalue);
 /* the reductions of the generator losses (multipassGAN-4x.py:754,764-765): out[0] = sum |a - b| (mode 0,
  * tf.reduce_mean(tf.abs(..)) after division by n) or sum (a - b)^2 (mode 1, 2 * tf.nn.l2_loss); b NULL = 0 */
 int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out);

@@ -109,6 +109,8 @@ PROTOTYPES = {
     "mpg_resize_nearest_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
     "mpg_avg_pool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mpg_lerp": (_I, [_P, _P, _P, _Z, _F, _P]),
+    "mpg_tensor_resample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mpg_tensor_resample_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mpg_pair_reduce": (_I, [_P, _P, _P, _Z, _I, _P]),
     "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _P, _F, _F, _F]),
 }

@@ -389,6 +389,66 @@ __global__ __launch_bounds__(256) void pair_reduce_kernel(const float* __restric
     if (threadIdx.x == 0) atomicAdd(out, red[0]);
 }
 
+// tensorResample (multipassGAN-4x.py:398-441), 2D: bilinear look-up of value[b] at pos[b,i,j] = (y, x) given in
+// cell-centred coordinates (sample k sits at k + 0.5).  floor / ceil indices are clamped to the grid when
+// `clamp` (the script default, :125) and the weights 1 - |p - 0.5 - idx| use the CLAMPED index, as the
+// reference does; without clamping samples outside the grid read zero.
+__device__ __forceinline__ void resample_taps(float p, int n, int clamp, int (&idx)[2], float (&wt)[2]) {
+    const float f = p - 0.5f;
+    int i0 = (int)floorf(f), i1 = i0 + 1;
+    if (clamp) {
+        i0 = min(max(i0, 0), n - 1);
+        i1 = min(max(i1, 0), n - 1);
+    }
+    idx[0] = i0; idx[1] = i1;
+    wt[0] = 1.f - fabsf(f - (float)i0);
+    wt[1] = 1.f - fabsf(f - (float)i1);
+}
+
+__global__ void resample_kernel(const float* __restrict__ v, const float* __restrict__ pos, int n, int h, int w, int c,
+                                int clamp, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const size_t pix = idx / c;
+    const int b = pix / ((size_t)h * w);
+    int iy[2], ix[2];
+    float wy[2], wx[2];
+    resample_taps(pos[pix * 2], h, clamp, iy, wy);
+    resample_taps(pos[pix * 2 + 1], w, clamp, ix, wx);
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (iy[a] >= 0 && iy[a] < h && ix[e] >= 0 && ix[e] < w)
+                s = fmaf(v[(((size_t)b * h + iy[a]) * w + ix[e]) * c + ch], wy[a] * wx[e], s);
+    out[idx] = s;
+}
+
+// gradient with respect to value: scatter-add of dy with the same taps (dv zeroed by the caller)
+__global__ void resample_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pos, int n, int h, int w,
+                                    int c, int clamp, float* __restrict__ dv) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const size_t pix = idx / c;
+    const int b = pix / ((size_t)h * w);
+    int iy[2], ix[2];
+    float wy[2], wx[2];
+    resample_taps(pos[pix * 2], h, clamp, iy, wy);
+    resample_taps(pos[pix * 2 + 1], w, clamp, ix, wx);
+    const float g = dy[idx];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (iy[a] >= 0 && iy[a] < h && ix[e] >= 0 && ix[e] < w)
+                atomicAdd(dv + (((size_t)b * h + iy[a]) * w + ix[e]) * c + ch, g * wy[a] * wx[e]);
+}
+
 int fill_geom(ConvGeom& g, int n, int h, int w, int cin, int cout, int kh, int kw, int sh, int sw) {
     g.n = n; g.h = h; g.w = w; g.cin = cin; g.cout = cout; g.kh = kh; g.kw = kw; g.sh = sh; g.sw = sw;
     g.oh = (h + sh - 1) / sh;
@@ -550,6 +610,28 @@ extern "C" int mpg_lerp(mpg_stream_t stream, const float* x, const float* y, siz
     if (n == 0) return MPG_OK;
     hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, x, y, n, t, out);
     MPG_LAUNCH_CHECK("lerp_kernel");
+}
+
+extern "C" int mpg_tensor_resample(mpg_stream_t stream, const float* value, const float* pos, int n, int h, int w,
+                                   int c, int clamp, float* out) {
+    MPG_REQUIRE(value && pos && out, "mpg_tensor_resample: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "mpg_tensor_resample: bad shape");
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(resample_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, value, pos, n, h, w, c,
+                       clamp, out);
+    MPG_LAUNCH_CHECK("resample_kernel");
+}
+
+extern "C" int mpg_tensor_resample_bwd(mpg_stream_t stream, const float* dy, const float* pos, int n, int h, int w,
+                                       int c, int clamp, float* dvalue) {
+    MPG_REQUIRE(dy && pos && dvalue, "mpg_tensor_resample_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "mpg_tensor_resample_bwd: bad shape");
+    const size_t total = (size_t)n * h * w * c;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = mpg::zero_async(dvalue, total * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_tensor_resample_bwd: zero");
+    hipLaunchKernelGGL(resample_bwd_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, dy, pos, n, h, w, c, clamp, dvalue);
+    MPG_LAUNCH_CHECK("resample_bwd_kernel");
 }
 
 extern "C" int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out) {

@@ -213,5 +213,25 @@ def disc_binclass(in_low, in_high, tileSizeLow, upRes, n_input, n_inputChannels,
         return gan.y(), d1, d2, d3, d4
 
 
+def disc_binclass_cond_tempo(in_high, tileSizeLow, upRes, n_t_channels=3, reuse=False, use_batch_norm=False,
+                             train=False, bn_decay=0.999):
+    """multipassGAN-4x.py:622-659 (2D branch): n_t_channels advected frames packed as channels -> logit"""
+    tileSizeHigh = tileSizeLow * upRes
+    with tf.variable_scope("discriminatorTempo", reuse=reuse):
+        in_high = tf.reshape(in_high, shape=[-1, tileSizeHigh, tileSizeHigh, n_t_channels])
+        filter = [4, 4]
+        gan = GAN(in_high, bn_decay=bn_decay)
+        gan.convolutional_layer(32, filter, lrelu, stride=[2], name="t_c1", reuse=reuse)
+        gan.convolutional_layer(64, filter, lrelu, stride=[2], name="t_c2", reuse=reuse, batch_norm=use_batch_norm,
+                                train=train)
+        gan.convolutional_layer(128, filter, lrelu, stride=[2], name="t_c3", reuse=reuse, batch_norm=use_batch_norm,
+                                train=train)
+        gan.convolutional_layer(256, filter, lrelu, stride=[1], name="t_c4", reuse=reuse, batch_norm=use_batch_norm,
+                                train=train)
+        gan.flatten()
+        gan.fully_connected_layer(1, None, name="t_l5")
+        return gan.y()
+
+
 def log2_int(v):
     return int(round(math.log(v, 2)))

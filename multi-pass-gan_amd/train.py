@@ -376,6 +376,21 @@ class PairLossFn(torch.autograd.Function):
         return (ga if ctx.needs_input_grad[0] else None), (-ga if ctx.needs_input_grad[1] else None), None
 
 
+class ResampleFn(torch.autograd.Function):
+    """tensorResample(value, pos) (multipassGAN-4x.py:398-441); pos is data, the gradient goes to value"""
+
+    @staticmethod
+    def forward(ctx, value, pos, clamp):
+        ctx.save_for_backward(pos)
+        ctx.clamp = clamp
+        return train_ops.tensor_resample(value, pos, clamp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pos,) = ctx.saved_tensors
+        return train_ops.tensor_resample_bwd(dy, pos, ctx.clamp), None, None
+
+
 class TrainSession(object):
     """Eager, differentiable evaluation of ``graph`` nodes; parameters are leaf tensors keyed by
     the TF variable path.  ``run(fetches, feeds)`` returns torch tensors that carry the tape."""
@@ -626,7 +641,8 @@ class Trainer4x(object):
 
     def __init__(self, tileSizeLow=16, upRes=4, n_inputChannels=4, batch_norm=True, upsampling_mode=2, device="cuda:0",
                  learning_rate=2e-4, beta1=0.5, lambda_l1=1.0, lambda2=0.0, lambda2_l=(1.0, 1.0, 1.0, 1.0),
-                 weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777, comm=None):
+                 weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777, comm=None,
+                 use_tempo=False, lambda_t=1.0, adv_flag=True, clamping=True):
         from . import nets
         from .session import VariableStore
         self.tileSizeLow, self.upRes, self.C = tileSizeLow, upRes, n_inputChannels
@@ -647,12 +663,27 @@ class Trainer4x(object):
                    upsampling_mode=upsampling_mode, use_batch_norm=batch_norm, train=True, bn_decay=bn_decay)
         self.disc = nets.disc_binclass(self.x_disc, self.y, **dkw)
         self.gen = nets.disc_binclass(self.x_disc, self.gen_part, reuse=True, **dkw)
+        # temporal discriminator (multipassGAN-4x.py:790-885): three advected frames as channels
+        self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
+        if use_tempo:
+            self.x_t = G.placeholder([None, self.n_input], name="x_t")
+            self.gen_part_t = nets.gen_resnet(self.x_t, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
+                                              reuse=True, use_batch_norm=batch_norm, train=True)
+            self.t_fake = G.placeholder([None, self.n_output * self.n_t], name="t_fake")
+            self.t_real = G.placeholder([None, self.n_output * self.n_t], name="t_real")
+            tk = dict(tileSizeLow=tileSizeLow, upRes=upRes, n_t_channels=self.n_t, use_batch_norm=batch_norm, train=True,
+                      bn_decay=bn_decay)
+            self.gen_t = nets.disc_binclass_cond_tempo(self.t_fake, reuse=False, **tk)
+            self.disc_t = nets.disc_binclass_cond_tempo(self.t_real, reuse=True, **tk)
         self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, bn_decay=bn_decay,
                                  device=device)
         self.g_var = self.sess.trainable("g_")
         self.d_var = self.sess.trainable("d_")
         self.opt_d = AdamTF(self.d_var, learning_rate, beta1, comm=comm)
         self.opt_g = AdamTF(self.g_var, learning_rate, beta1, comm=comm)
+        if use_tempo:
+            self.t_var = {n: p for n, p in self.sess.trainable("t_").items() if n.startswith("discriminatorTempo")}
+            self.opt_t = AdamTF(self.t_var, learning_rate, beta1, comm=comm)
 
     def losses(self, batch_xs, batch_ys):
         """-> dict of the loss tensors of multipassGAN-4x.py:744-768 (one forward of G, D(real), D(fake))"""
@@ -675,6 +706,50 @@ class Trainer4x(object):
         L["gen_l1_loss"] = PairLossFn.apply(y, gen_part, 0) / float(gen_part.numel())
         L["gen_loss_complete"] = L["gen_loss"] + L["gen_l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
         L["gen_part"] = gen_part
+        return L
+
+    # ------------------------------------------------------------------ temporal branch
+    def _frames_as_channels(self, frames, y_pos):
+        """[3B, n_output] frame rows (+ look-up positions [3B, 2 n_output]) -> [B, n_output * 3]: advect every
+        frame to the centre time with tensorResample when adv_flag (:801-812), then pack the n_t frames of a
+        tile as channels (reshape [-1, n_t, n_output], transpose (0, 2, 1), :813-814)"""
+        th = self.tileSizeHigh
+        v = frames.reshape(-1, th, th, 1)
+        if self.adv_flag:
+            pos = torch.as_tensor(y_pos, dtype=torch.float32, device=v.device).reshape(-1, th, th, 2)
+            v = ResampleFn.apply(v, pos, self.clamping)
+        return v.reshape(-1, self.n_t, self.n_output).permute(0, 2, 1).reshape(-1, self.n_output * self.n_t)
+
+    def tempo_losses(self, batch_xts, batch_yts, batch_y_pos=None):
+        """-> t_disc_loss, t_gen_loss (:834-866) for a coherent batch from TileCreator.selectRandomTempoTiles"""
+        dev = self.sess.device
+        xts = torch.as_tensor(batch_xts, dtype=torch.float32, device=dev)
+        yts = torch.as_tensor(batch_yts, dtype=torch.float32, device=dev)
+        gen_part_t = self.sess.run([self.gen_part_t], {self.x_t: xts})[0]
+        fake = self._frames_as_channels(gen_part_t, batch_y_pos)
+        real = self._frames_as_channels(yts, batch_y_pos)
+        gen_t, disc_t = self.sess.run([self.gen_t, self.disc_t], {self.t_fake: fake, self.t_real: real})
+        L = {}
+        L["t_disc_loss_disc"] = sigmoid_ce(disc_t, torch.ones_like(disc_t))
+        L["t_disc_loss_gen"] = sigmoid_ce(gen_t, torch.zeros_like(gen_t))
+        L["t_disc_loss"] = L["t_disc_loss_disc"] * self.weight_dld + L["t_disc_loss_gen"]
+        L["t_gen_loss"] = sigmoid_ce(gen_t, torch.ones_like(gen_t))
+        return L
+
+    def tempo_disc_step(self, batch_xts, batch_yts, batch_y_pos=None, advance=True):
+        L = self.tempo_losses(batch_xts, batch_yts, batch_y_pos)
+        grads = torch.autograd.grad(L["t_disc_loss"], self.opt_t.params, allow_unused=True)
+        self.opt_t.step(grads, advance=advance)
+        return L
+
+    def gen_step_tempo(self, batch_xs, batch_ys, batch_xts, batch_yts, batch_y_pos=None, advance=True):
+        """generator update with the temporal term: gen_loss_complete + lambda_t * t_gen_loss (:866-868,897-899)"""
+        L = self.losses(batch_xs, batch_ys)
+        Lt = self.tempo_losses(batch_xts, batch_yts, batch_y_pos)
+        L.update(Lt)
+        L["gen_loss_complete"] = L["gen_loss_complete"] + self.kt * Lt["t_gen_loss"]
+        grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
+        self.opt_g.step(grads, advance=advance)
         return L
 
     def disc_step(self, batch_xs, batch_ys, advance=True):
@@ -723,12 +798,16 @@ class Trainer4x(object):
         self._graph.replay()
         return self._gout
 
-    def train_step(self, batch_xs, batch_ys, discRuns=1, genRuns=1):
-        """one iteration of the reference loop (:1317-1356): returns (disc_loss, gen_loss_complete) device scalars"""
+    def train_step(self, batch_xs, batch_ys, discRuns=1, genRuns=1, tempo=None):
+        """one iteration of the reference loop (:1317-1356): returns (disc_loss, gen_loss_complete) device scalars.
+        tempo = (batch_xts, batch_yts, batch_y_pos) adds the temporal discriminator update and loss term."""
         for _ in range(discRuns):
             Ld = self.disc_step(batch_xs, batch_ys)
+        if tempo is not None:
+            for _ in range(discRuns):
+                self.tempo_disc_step(*tempo)
         for _ in range(genRuns):
-            Lg = self.gen_step(batch_xs, batch_ys)
+            Lg = self.gen_step_tempo(batch_xs, batch_ys, *tempo) if tempo is not None else self.gen_step(batch_xs, batch_ys)
         # detached: holding a loss would keep the tape (and its stream bookkeeping) alive across iterations
         return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()
 

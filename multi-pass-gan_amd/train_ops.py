@@ -162,6 +162,29 @@ def lerp(x, y, t):
     return out
 
 
+def tensor_resample(value, pos, clamp=True):
+    """tensorResample (multipassGAN-4x.py:398-441): value [n,h,w,c], pos [n,h,w,2] = (y, x)"""
+    lib = _lib.load()
+    value, pos = _cont(value, "value"), _cont(pos, "pos")
+    n, h, w, c = value.shape
+    if tuple(pos.shape) != (n, h, w, 2):
+        raise _lib.MpgError("tensor_resample: pos shape %s does not match value %s" % (tuple(pos.shape), tuple(value.shape)))
+    out = torch.empty_like(value)
+    _lib.check(lib.mpg_tensor_resample(_stream(), _ptr(value), _ptr(pos), n, h, w, c, int(bool(clamp)), _ptr(out)),
+               "mpg_tensor_resample")
+    return out
+
+
+def tensor_resample_bwd(dy, pos, clamp=True):
+    lib = _lib.load()
+    dy, pos = _cont(dy, "dy"), _cont(pos, "pos")
+    n, h, w, c = dy.shape
+    dv = torch.empty_like(dy)
+    _lib.check(lib.mpg_tensor_resample_bwd(_stream(), _ptr(dy), _ptr(pos), n, h, w, c, int(bool(clamp)), _ptr(dv)),
+               "mpg_tensor_resample_bwd")
+    return dv
+
+
 def pair_reduce(a, b, mode):
     """0-dim tensor: sum |a - b| (mode 0) or sum (a - b)^2 (mode 1)"""
     lib = _lib.load()

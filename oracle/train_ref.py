@@ -122,6 +122,63 @@ def losses_4x(p, batch_xs, batch_ys, tile_low, up_res, channels, batch_norm=True
     return L
 
 
+def tensor_resample(value_nhwc, pos, clamp=True):
+    """tensorResample (multipassGAN-4x.py:398-441), 2D: value [N,H,W,C] tensor, pos [N,H,W,2] = (y, x)"""
+    n, h, w, c = value_nhwc.shape
+    pos = torch.as_tensor(np.asarray(pos), dtype=DT).reshape(n, h, w, 2)
+    f = pos - 0.5
+    fl = torch.floor(f).long()
+    out = 0.0
+    bidx = torch.arange(n).view(n, 1, 1).expand(n, h, w)
+    lim = torch.tensor([h - 1, w - 1])
+    for ay in (0, 1):
+        for ax in (0, 1):
+            idx = fl + torch.tensor([ay, ax])
+            inside = ((idx >= 0) & (idx <= lim)).all(dim=-1)
+            if clamp:
+                idx = torch.minimum(torch.clamp(idx, min=0), lim)
+                inside = torch.ones_like(inside)
+            wgt = (1.0 - (f - idx.to(DT)).abs()).prod(dim=-1, keepdim=True)
+            safe = torch.minimum(torch.clamp(idx, min=0), lim)
+            g = value_nhwc[bidx, safe[..., 0], safe[..., 1]]
+            out = out + g * wgt * inside.unsqueeze(-1).to(DT)
+    return out
+
+
+def disc_tempo(p, x_nchw, batch_norm=True):
+    """disc_binclass_cond_tempo (multipassGAN-4x.py:622-659): [N,3,H,W] -> logit"""
+    sc = "discriminatorTempo/"
+    t1, _ = conv_layer(p, sc + "t_c1", x_nchw, "lrelu", 2, False)
+    t2, _ = conv_layer(p, sc + "t_c2", t1, "lrelu", 2, batch_norm)
+    t3, _ = conv_layer(p, sc + "t_c3", t2, "lrelu", 2, batch_norm)
+    t4, _ = conv_layer(p, sc + "t_c4", t3, "lrelu", 1, batch_norm)
+    flat = t4.permute(0, 2, 3, 1).reshape(t4.shape[0], -1)
+    w = p[sc + "t_l5/weight"]
+    ws = float(np.float32(math.sqrt(2.0) / np.sqrt(w.shape[0])))
+    return flat @ (w * ws) + p[sc + "t_l5/bias"]
+
+
+def tempo_losses_4x(p, batch_xts, batch_yts, batch_y_pos, tile_low, up_res, channels, batch_norm=True, weight_dld=1.0,
+                    adv=True, clamp=True):
+    """t_disc_loss / t_gen_loss of multipassGAN-4x.py:790-866 for [3B, .] coherent frame rows"""
+    th = tile_low * up_res
+    x = torch.tensor(np.asarray(batch_xts), dtype=DT).reshape(-1, tile_low, tile_low, channels).permute(0, 3, 1, 2)
+    gen_t = gen_resnet(p, x, up_res, 2, batch_norm)                       # [3B,1,H,W]
+
+    def pack(frames_nhwc):
+        v = tensor_resample(frames_nhwc, batch_y_pos, clamp) if adv else frames_nhwc
+        v = v.reshape(-1, 3, th * th).permute(0, 2, 1)                    # batch, n_output, frames
+        return v.reshape(-1, th, th, 3).permute(0, 3, 1, 2)
+
+    fake = pack(gen_t.permute(0, 2, 3, 1))
+    real = pack(torch.tensor(np.asarray(batch_yts), dtype=DT).reshape(-1, th, th, 1))
+    g_t, d_t = disc_tempo(p, fake, batch_norm), disc_tempo(p, real, batch_norm)
+    L = {}
+    L["t_disc_loss"] = sigmoid_ce(d_t, torch.ones_like(d_t)) * weight_dld + sigmoid_ce(g_t, torch.zeros_like(g_t))
+    L["t_gen_loss"] = sigmoid_ce(g_t, torch.ones_like(g_t))
+    return L
+
+
 def grads(loss, p, tag):
     names = sorted(n for n, t in p.items() if t.requires_grad and tag in n)
     gs = torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True, retain_graph=True)

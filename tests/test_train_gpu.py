@@ -329,3 +329,80 @@ def test_graphed_iteration_matches_eager():
         assert (diff > 1e-4).mean() <= 0.01, (nme, float((diff > 1e-4).mean()))
         assert diff.mean() <= 2e-5, (nme, float(diff.mean()))
     assert np.isfinite(float(d)) and np.isfinite(float(g))
+
+
+@pytest.mark.parametrize("clamp", [True, False])
+def test_tensor_resample_forward_backward(clamp):
+    """tensorResample (advection look-up of the temporal discriminator inputs) incl. positions outside the grid"""
+    from mpgan_amd.train import ResampleFn
+    rng = np.random.default_rng(21)
+    n, h, w, c = 3, 12, 10, 2
+    v = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    yy, xx = np.meshgrid(np.arange(h) + 0.5, np.arange(w) + 0.5, indexing="ij")
+    pos = np.stack([yy, xx], -1)[None] + rng.normal(0, 1.5, (n, h, w, 2))
+    pos = pos.astype(np.float32)
+    g = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    vr = torch.tensor(v, dtype=torch.float64, requires_grad=True)
+    outr = TR.tensor_resample(vr, pos, clamp)
+    outr.backward(torch.tensor(g, dtype=torch.float64))
+    vt = dev(v).requires_grad_(True)
+    out = ResampleFn.apply(vt, dev(pos), clamp)
+    out.backward(dev(g))
+    assert rel(out.detach().cpu().numpy(), outr.detach().numpy()) < 1e-6
+    assert rel(vt.grad.cpu().numpy(), vr.grad.numpy()) < 1e-6
+    # identity positions return the field itself -- except in the last row / column when clamping: the ceil
+    # index is clamped onto the floor index and both keep weight 1 (the reference computes the weights from
+    # the clamped indices, multipassGAN-4x.py:408-430), so those samples are counted twice
+    ident = np.broadcast_to(np.stack([yy, xx], -1)[None], (n, h, w, 2)).astype(np.float32)
+    got = ResampleFn.apply(dev(v), dev(np.ascontiguousarray(ident)), clamp).cpu().numpy()
+    assert np.allclose(got[:, :-1, :-1], v[:, :-1, :-1], atol=1e-6)
+    if clamp:
+        assert np.allclose(got[:, -1, :-1], 2 * v[:, -1, :-1], atol=1e-5) and np.allclose(got[:, -1, -1], 4 * v[:, -1, -1], atol=1e-5)
+
+
+def test_temporal_discriminator_losses_and_gradients():
+    """coherent triples from TileCreator.selectRandomTempoTiles -> advection -> disc_binclass_cond_tempo"""
+    import contextlib
+    import io
+    import random
+    from mpgan_amd import tilecreator_t as tc
+    from mpgan_amd.train import Trainer4x
+    tile, C, up = 8, 4, 4
+    rng = np.random.default_rng(31)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tiCr = tc.TileCreator(tileSizeLow=tile, simSizeLow=16, upres=up, dim=2, dim_t=3, densityMinimum=0.0,
+                              channelLayout_low="d,vx,vy,vz", channelLayout_high="d")
+        tiCr.addData(rng.random((4, 1, 16, 16, 12)).astype(np.float32), rng.random((4, 1, 64, 64, 3)).astype(np.float32))
+    random.seed(1)
+    xts, yts, ypos = tiCr.selectRandomTempoTiles(6, True, False, n_t=3, dt=0.5)
+    assert xts.shape == (6, tile * tile * C) and yts.shape == (6, 32 * 32) and ypos.shape == (6, 2 * 32 * 32)
+    tr = Trainer4x(tileSizeLow=tile, upRes=up, n_inputChannels=C, batch_norm=True, device=DEV, seed=5, use_tempo=True)
+    ps = ParamSource(seed=5)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in tr.graph.variables.items()}
+    with torch.no_grad():
+        for n, t in tr.sess.params.items():
+            t.copy_(dev(params[n]))
+    p = TR.to_params(params)
+    L = tr.tempo_losses(xts, yts, ypos)
+    Lr = TR.tempo_losses_4x(p, xts, yts, ypos, tile, up, C)
+    for k in ("t_disc_loss", "t_gen_loss"):
+        a, b = float(L[k].detach()), float(Lr[k].detach())
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
+    gt = torch.autograd.grad(L["t_disc_loss"], tr.opt_t.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["t_gen_loss"], tr.opt_g.params, allow_unused=True)
+    rt = TR.grads(Lr["t_disc_loss"], p, "t_")
+    rt = {k: v for k, v in rt.items() if k.startswith("discriminatorTempo")}
+    rg = TR.grads(Lr["t_gen_loss"], p, "g_")
+    assert sorted(rt) == tr.opt_t.names
+    bn_bias = BN_BIASES | {"discriminatorTempo/t_c%d/bias" % i for i in (2, 3, 4)}
+    for names, got, want in ((tr.opt_t.names, gt, rt), (tr.opt_g.names, gg, rg)):
+        for nme, g in zip(names, got):
+            if nme in bn_bias:
+                continue
+            assert rel(g.cpu().numpy(), want[nme]) < 1e-3, nme
+    # one full iteration with the temporal branch
+    xs, ys = rng.random((4, tile * tile * C)).astype(np.float32), rng.random((4, 32 * 32)).astype(np.float32)
+    before = {n: t.detach().clone() for n, t in tr.sess.params.items()}
+    d, g = tr.train_step(xs, ys, tempo=(xts, yts, ypos))
+    assert np.isfinite(float(d)) and np.isfinite(float(g))
+    assert all(not torch.equal(tr.sess.params[n].detach(), before[n]) for n in tr.opt_t.names if n not in bn_bias)
