@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""4x driver, output mode (``out 1``): same ``name value`` command line and files as the
-reference's GAN/multipassGAN-4x.py (params :32-144, generate3DUniForNewNetwork :1090-1169,
-output loop :1634-1646).  One network per invocation, the intermediate volume travels through
-``density_low_2x2_%04d.uni`` exactly as in the reference (example_run_output.py:4-8):
+"""4x driver: same ``name value`` command line and files as the reference's GAN/multipassGAN-4x.py
+(params :32-144).
+
+Output mode (``out 1``; generate3DUniForNewNetwork :1090-1169, output loop :1634-1646): one network per
+invocation, the intermediate volume travels through ``density_low_2x2_%04d.uni`` exactly as in the
+reference (example_run_output.py:4-8):
 
   upsamplingMode 2, upsampledData 0 : zoom z, slices along z  -> density_low_2x2_%04d.uni
   upsamplingMode 1, upsampledData 1 : slices along x          -> density_low_1x1_%04d.uni
 
-Training mode (``out 0``) is not part of this round's scope (SURVEY.md section 8f ordering).
+Training mode (``out 0``) trains the first network (upsamplingMode 2, upsampledData 0) the way the
+reference loop does (:196-300 data, :728-902 graph, :1300-1360 iteration): FluidDataLoader slices ->
+TileCreator tiles (augmentation, coherent triples) -> ``train.Trainer4x`` (spatial + temporal
+discriminator) -> ``basePath/test_%04d/model_%04d.ckpt.npz``.
 """
 import os
 import sys
@@ -57,9 +62,138 @@ upsampling_mode, upsampled_data = int(P["upsamplingMode"]), int(P["upsampledData
 generateUni = int(P["genUni"])
 batch_norm = int(P["batchNorm"]) > 0
 load_model_test, load_model_no = int(P["load_model_test"]), int(P["load_model_no"])
+
+
+def train_main():
+    """multipassGAN-4x.py with `out 0`, first network"""
+    from mpgan_amd import tilecreator_t as tc
+    from mpgan_amd.train import Trainer4x
+    if int(P["upsamplingMode"]) != 2 or int(P["upsampledData"]) or int(P["dataDim"]) != 2:
+        print("ERROR: training is implemented for the first network (upsamplingMode 2, upsampledData 0, dataDim 2)")
+        exit(1)
+    if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
+        print("ERROR: vorticity / flag / k-eps inputs and premade tiles are not supported")
+        exit(1)
+    tileSizeLow, toSim = int(P["tileSize"]), int(P["toSim"])
+    toSim = fromSim if toSim == -1 else toSim
+    randSeed = int(P["randSeed"])
+    kt, kt_l = float(P["lambda_t"]), float(P["lambda_t_l2"])
+    useTempoD = kt > 1e-6                                              # 4x.py:147-152
+    if kt_l > 1e-6:
+        print("ERROR: the l2 temporal loss (lambda_t_l2) is not built; use lambda_t")
+        exit(1)
+    channelLayout_low, mfl, mfh = 'd', ["density"], ["density"]
+    if useVelocities:
+        channelLayout_low += ',vx,vy,vz'
+        mfl = mfl + ["velocity"]
+    dirIDs = np.linspace(fromSim, toSim, (toSim - fromSim + 1), dtype='int16')
+    data_fraction = float(P["data_fraction"])
+    if not useTempoD:
+        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, simSizeLow=simSizeLow, dim=2, dim_t=1, channelLayout_low=channelLayout_low,
+                              upres=upRes, premadeTiles=False, channelLayout_high='d')
+        fl = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
+                                 conv_slices=True, conv_axis=0, select_random=0.1, density_threshold=0.002,
+                                 axis_scaling_y=[1.0 / upRes, 1, 1, 1], axis_scaling=[1, 1, 1, 1],
+                                 filename="density_low_%04d.uni", filename_index_min=frame_min, oldNamingScheme=False,
+                                 filename_y="density_high_%04d.uni", filename_index_max=frame_max, indices=dirIDs,
+                                 data_fraction=data_fraction, multi_file_list=mfl, multi_file_list_y=mfh)
+        n_t = 1
+    else:                                                              # three coherent frames per sample (:214-262)
+        n_t = 3
+        mol = [o for o in range(3) for _ in mfl]
+        moh = [o for o in range(3) for _ in mfh]
+        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.005, channelLayout_high='d', simSizeLow=simSizeLow,
+                              dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=upRes, premadeTiles=False)
+        fl = FDL.FluidDataLoader(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
+                                 conv_slices=True, conv_axis=0, select_random=0.1, density_threshold=0.002,
+                                 axis_scaling_y=[1.0 / upRes, 1, 1, 1], axis_scaling=[1, 1, 1, 1],
+                                 filename="density_low_%04d.uni", oldNamingScheme=False, filename_y="density_high_%04d.uni",
+                                 filename_index_max=frame_max, filename_index_min=frame_min, indices=dirIDs,
+                                 data_fraction=data_fraction, multi_file_list=mfl * 3, multi_file_idxOff=mol,
+                                 multi_file_list_y=mfh * 3, multi_file_idxOff_y=moh)
+    if int(P["dataAugmentation"]):
+        tiCr.initDataAugmentation(rot=int(P["rot"]), minScale=float(P["minScale"]), maxScale=float(P["maxScale"]),
+                                  flip=int(P["flip"]))
+    x, y, _ = fl.get()
+    x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_ch * n_t)          # :288-290
+    y = y.reshape(-1, 1, simSizeHigh, simSizeHigh, n_t)
+    tiCr.addData(x, y)
+    np.random.seed(randSeed)
+    test_path, _ = ph.getNextTestPath(int(P["testPathStartNo"]), basePath)
+    print("\nUsing parameters:\n" + ph.paramsToString())
+    ph.writeParams(test_path + "params.json")
+    batch = int(P["batchSize"])
+    trainer = Trainer4x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_ch, batch_norm=batch_norm,
+                        upsampling_mode=2, device=device, learning_rate=float(P["learningRate"]),
+                        beta1=float(P["adam_beta1"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
+                        lambda2_l=tuple(float(P["lambda2_l%d" % i]) for i in (1, 2, 3, 4)),
+                        weight_dld=float(P["weight_dld"]), bn_decay=float(P["bnDecay"]), seed=randSeed,
+                        use_tempo=useTempoD, lambda_t=kt, adv_flag=int(P["adv_flag"]) > 0, clamping=int(P["clamping"]) > 0)
+    if load_model_test >= 0:
+        params = checkpoint.load(checkpoint.model_path(basePath, load_model_test, load_model_no))
+        with torch.no_grad():
+            for n_, t_ in trainer.sess.params.items():
+                if n_ in params:
+                    t_.copy_(torch.as_tensor(params[n_], device=t_.device))
+        print("Model restored.")
+    aug = int(P["dataAugmentation"]) > 0
+    n_in, n_out = tileSizeLow * tileSizeLow * n_ch, (tileSizeLow * upRes) ** 2
+
+    def getinput():
+        bx, by = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
+        return bx.reshape(-1, n_in), by.reshape(-1, n_out)
+
+    def save(no):
+        trainer.sess.sync_to_store()
+        checkpoint.save(test_path + 'model_%04d.ckpt' % no, trainer.sess.vars.numpy())
+        print('Saved Model with number %d' % no)
+
+    epochs = int(P["trainingEpochs"])
+    discRuns, genRuns = int(P["discRuns"]), int(P["genRuns"])
+    outputInterval, saveInterval = int(P["outputInterval"]), int(P["saveInterval"])
+    save_no, t0 = 0, time.time()
+    avg_d = avg_g = avg_l1 = 0.0
+    print('\n*****TRAINING STARTED*****\n')
+    for epoch in range(epochs):
+        for _ in range(discRuns):
+            bx, by = getinput()
+            avg_d += float(trainer.disc_step(bx, by)["disc_loss"].detach())
+        tempo = None
+        if useTempoD:
+            for _ in range(discRuns):
+                tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
+                trainer.tempo_disc_step(*tempo)
+        for _ in range(genRuns):
+            bx, by = getinput()
+            if useTempoD:
+                tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
+                L = trainer.gen_step_tempo(bx, by, *tempo)
+            else:
+                L = trainer.gen_step(bx, by)
+            avg_g += float(L["gen_loss"].detach())
+            avg_l1 += float(L["gen_l1_loss"].detach())
+        if (epoch + 1) % outputInterval == 0:
+            k = float(outputInterval)
+            print('\nEpoch {:05d}/{}, Cost:'.format(epoch + 1, epochs))
+            print('\tdisc: loss: train_loss={:.6f}'.format(avg_d / (k * discRuns)))
+            print('\tgen: loss: train={:.6f} L1={:.6f}'.format(avg_g / (k * genRuns), avg_l1 / (k * genRuns)))
+            print('\t{} epochs took {:.2f} seconds.'.format(outputInterval, time.time() - t0))
+            avg_d = avg_g = avg_l1 = 0.0
+            t0 = time.time()
+        if (epoch + 1) % saveInterval == 0:
+            save(save_no)
+            save_no += 1
+    save(save_no)
+    print('\n*****TRAINING FINISHED*****')
+    print('Test path: %s' % test_path)
+
+
 if not outputOnly:
-    print("ERROR: training mode is not implemented in this build; run with `out 1`")
-    exit(1)
+    n_ch = 4 if useVelocities else 1
+    simSizeHigh = simSizeLow * upRes
+    device = "cuda:0"
+    train_main()
+    exit(0)
 if upsampling_mode not in (1, 2) or int(P["dataDim"]) != 2 or int(P["useAvgDepool"]):
     print("ERROR: only upsamplingMode 2 (first network) and 1 (second network) of the 2D slice path are implemented")
     exit(1)

@@ -89,3 +89,46 @@ def test_8x_out_driver(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "GAN", "multipassGAN-out.py"), "nonsense", "1"],
                        capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "not used" in r.stdout
+
+
+@pytest.mark.parametrize("lambda_t", [0.0, 1.0])
+def test_4x_training_driver(tmp_path, lambda_t):
+    """`out 0`: FluidDataLoader slices -> TileCreator -> Trainer4x (with / without the temporal discriminator)
+    -> model_%04d.ckpt.npz under the reference's variable names, which the output mode then loads"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import checkpoint, uniio
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, up, frames = 16, 4, 9       # the loader keeps int(slices * 0.1) slices per frame: at least 10 slices
+    d = tmp_path / "data" / "sim_1005"
+    d.mkdir(parents=True)
+    (tmp_path / "models").mkdir()
+    for f in range(frames):
+        v = synthetic_volume(sim, 4, f)
+        hi = synthetic_volume(sim * up, 1, 100 + f)
+        uniio.writeUni(str(d / ("density_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim), v[..., 0:1] + 0.05)
+        uniio.writeUni(str(d / ("velocity_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim, vec3=True), v[..., 1:4])
+        uniio.writeUni(str(d / ("density_high_%04d.uni" % f)), uniio.make_header(sim * up, sim * up, sim * up), hi + 0.05)
+    args = ["upRes", up, "out", 0, "tileSize", 8, "simSize", sim, "fromSim", 1005, "toSim", 1005, "dataDim", 2,
+            "useVelocities", 1, "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/",
+            "frame_min", 0, "frame_max", 6, "genModel", "gen_resnet", "discModel", "disc_binclass", "randSeed", 42,
+            "batchSize", 4, "trainingEpochs", 3, "outputInterval", 1, "saveInterval", 2, "lambda", 5.0, "lambda_t", lambda_t,
+            "data_fraction", 1.0, "dataAugmentation", 0, "upsamplingMode", 2, "upsampledData", 0, "adam_beta1", 0.5,
+            "learningRate", 0.0002, "batchNorm", 1]
+    out = _run("multipassGAN-4x.py", args, str(tmp_path))
+    assert "TRAINING FINISHED" in out and "Epoch 00003/3" in out
+    test_dir = tmp_path / "models" / "test_0000"
+    assert (test_dir / "params.json").exists()
+    p0 = checkpoint.load(str(test_dir / "model_0000.ckpt"))
+    p1 = checkpoint.load(str(test_dir / "model_0001.ckpt"))
+    assert "generator/g_cB1/weight" in p1 and p1["generator/g_cB1/weight"].shape == (5, 5, 128, 128)
+    assert ("discriminatorTempo/t_c1/weight" in p1) == (lambda_t > 0)
+    assert not np.array_equal(p0["generator/g_cB1/weight"], p1["generator/g_cB1/weight"])
+    assert all(np.isfinite(v).all() for v in p1.values())
+    # the trained generator runs in output mode
+    _run("multipassGAN-4x.py", ["upRes", up, "out", 1, "tileSize", sim, "simSize", sim, "fromSim", 1005, "toSim", 1005,
+                                "dataDim", 2, "useVelocities", 1, "basePath", str(tmp_path / "models") + "/",
+                                "packedSimPath", str(tmp_path / "data") + "/", "frame_min", 0, "frame_max", 1, "genUni", 1,
+                                "genModel", "gen_resnet", "load_model_test", 0, "load_model_no", 1, "upsamplingMode", 2,
+                                "upsampledData", 0, "randSeed", 42], str(tmp_path))
+    h, v = uniio.readUni(str(d / "density_low_2x2_0000.uni"))
+    assert v.shape == (64, 64, 64, 1) and np.isfinite(v).all()
