@@ -235,6 +235,42 @@ def test_conv2d_fused_upsample_concat_postadd(gpu_ops):
     assert rel_l2(y2.cpu().numpy(), ref2) < 2e-5
 
 
+@pytest.mark.parametrize("prec,tol", [(3, 1e-5), (2, 1.5e-4), (1, 1e-5)])
+def test_conv_small_kernel_paths(gpu_ops, prec, tol):
+    """layers with <= 8 input and output channels run on conv_small_kernel: ragged image, two segments with a
+    fused x4 nearest upsample (resBlock 0 of pass 1: 5x5 2->8 + 1x1 shortcut 1->8), G8 outputs of both
+    flavours chained into the next small layer (8->2) and a 1-channel output"""
+    rng = _rng(17)
+    n, hl, wl, up = 2, 5, 11, 4
+    h, w = hl * up, wl * up                        # 20 x 44: partial 32 x 8 tiles in both directions
+    a_low = rng.standard_normal((n, hl, wl, 2)).astype(np.float32)
+    x_low = rng.standard_normal((n, hl, wl, 1)).astype(np.float32)
+    wb = rng.standard_normal((5, 5, 2, 8)).astype(np.float32)
+    ws = rng.standard_normal((1, 1, 1, 8)).astype(np.float32)
+    b8 = rng.standard_normal(8).astype(np.float32)
+    w2 = rng.standard_normal((5, 5, 8, 2)).astype(np.float32)
+    w1 = rng.standard_normal((3, 3, 2, 1)).astype(np.float32)
+    sb, ss, s2, s1 = (float(O.wscale(t.shape)) for t in (wb, ws, w2, w1))
+    a_up, x_up = O.resize_nearest_tf1(a_low, h, w), O.resize_nearest_tf1(x_low, h, w)
+    r8 = O.relu(O.bias_add(O.conv2d_same(a_up, wb * np.float32(sb)) + O.conv2d_same(x_up, ws * np.float32(ss)), b8))
+    r2 = O.conv2d_same(r8, w2 * np.float32(s2))
+    r1 = O.activation(O.conv2d_same(r2, w1 * np.float32(s1)), "lrelu")
+    pkb = gpu_ops.pack_conv_weights(_t(wb), wscale=sb, prec=prec)
+    pks = gpu_ops.pack_conv_weights(_t(ws), wscale=ss, prec=prec)
+    f8 = prec == 2
+    y8, g8 = gpu_ops.conv2d_fused([gpu_ops.Segment(_t(a_low), pkb, up_log2=2), gpu_ops.Segment(_t(x_low), pks, up_log2=2)],
+                                  (h, w), bias=_t(b8), act="relu", want_f32=True, want_g8=not f8, want_g8c=f8)
+    assert rel_l2(y8.cpu().numpy(), r8) < tol
+    g2 = gpu_ops.conv2d_fused([gpu_ops.Segment(g8, gpu_ops.pack_conv_weights(_t(w2), wscale=s2, prec=prec))], (h, w),
+                              want_f32=False, want_g8=not f8, want_g8c=f8)
+    y1 = gpu_ops.conv2d_fused([gpu_ops.Segment(g2, gpu_ops.pack_conv_weights(_t(w1), wscale=s1, prec=prec))], (h, w),
+                              act="lrelu")
+    assert y1.shape == (n, h, w, 1)
+    if not f8:
+        assert rel_l2(gpu_ops.from_g8(g2).cpu().numpy(), r2) < tol
+    assert rel_l2(y1.cpu().numpy(), r1) < (6e-4 if f8 else tol)      # F8C storage between layers: hi16 + fp8 correction
+
+
 @pytest.mark.parametrize("stride,k,cin,cout", [(1, 5, 3, 6), (2, 4, 2, 32), (2, 4, 32, 64), (1, 4, 128, 16), (2, 3, 5, 7)])
 def test_conv2d_direct(gpu_ops, stride, k, cin, cout):
     rng = _rng(17 + k + stride)
