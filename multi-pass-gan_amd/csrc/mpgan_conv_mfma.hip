@@ -712,6 +712,7 @@ constexpr int SM_TW = 32, SM_TH = 8;
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[(SM_TH + 6) * (SM_TW + 6) * 8];
+    __shared__ __attribute__((aligned(16))) float wl[49 * 64];      // the segment's table: LDS broadcasts instead of scalar loads
     const int tid = threadIdx.x;
     const int tx = tid % SM_TW, ty = tid / SM_TW;
     const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
@@ -725,6 +726,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
         const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
         const int tw = SM_TW + g.kw - 1, th = SM_TH + g.kh - 1;
         if (s > 0) __syncthreads();
+        for (int p = tid; p < g.kh * g.kw * 64; p += 256) wl[p] = g.w[p];
         for (int p = tid; p < tw * th; p += 256) {
             const int hy = p / tw, hx = p - hy * tw;
             const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             for (int kx = 0; kx < g.kw; ++kx) {
                 const float4* src = reinterpret_cast<const float4*>(tile + ((ty + ky) * tw + tx + kx) * 8);
                 const float4 lo4 = src[0];
-                const float* wt = g.w + (ky * g.kw + kx) * 64;
+                const float* wt = wl + (ky * g.kw + kx) * 64;
                 float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, 0.f, 0.f, 0.f, 0.f};
                 if (g.cin > 4) {
                     const float4 hi4 = src[1];
@@ -753,8 +755,21 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
 #pragma unroll
                 for (int ci = 0; ci < 8; ++ci) {
                     if (ci < g.cin) {
+                        float wv[8];
+                        if (COUT > 4) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(wt + ci * 8);
+                            const float4 w1 = *reinterpret_cast<const float4*>(wt + ci * 8 + 4);
+                            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w;
+                            wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+                        } else if (COUT > 2) {
+                            const float4 w0 = *reinterpret_cast<const float4*>(wt + ci * 8);
+                            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w;
+                        } else {
+                            const float2 w0 = *reinterpret_cast<const float2*>(wt + ci * 8);
+                            wv[0] = w0.x; wv[1] = w0.y;
+                        }
 #pragma unroll
-                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wt[ci * 8 + co], acc[co]);
+                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wv[co], acc[co]);
                     }
                 }
             }
