@@ -267,15 +267,6 @@ __global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const
     // a contiguous run of tiles => neighbouring halos hit the same L2.
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    // Stagger the first round of blocks by up to ~STAG us.  Every CU runs the same amount of work per tile, so
-    // without it all CUs reach their epilogues together and the stores of a round (33 MB at NT = 4) hit HBM as
-    // one burst that every CU then waits for (s_endpgm drains the stores); offset starts keep the bursts apart.
-    if (a.dbg & 4) {
-        if (blockIdx.x < 256) {
-            const int d = (blockIdx.x * 37) & 15;
-            for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int tx = bid % a.tiles_x;
     const int t2 = bid / a.tiles_x;
@@ -446,12 +437,6 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 
     int bid = blockIdx.x;
     const int nblk = gridDim.x;
-    if (a.dbg & 4) {        // see conv_mfma_kernel: staggered first round
-        if (blockIdx.x < 256) {
-            const int d = (blockIdx.x * 37) & 15;
-            for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(32);
-        }
-    }
     if ((nblk & 7) == 0) bid = (bid & 7) * (nblk >> 3) + (bid >> 3);
     const int tx = bid % a.tiles_x;
     const int t2 = bid / a.tiles_x;
