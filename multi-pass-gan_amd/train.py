@@ -821,7 +821,8 @@ class Trainer8x(object):
 
     def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
-                 prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999):
+                 prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999, use_tempo=False, lambda_t=1.0,
+                 adv_flag=True, clamping=True):
         from . import nets8x
         from .session import VariableStore
         self.cfg = cfg
@@ -843,13 +844,29 @@ class Trainer8x(object):
         self.gen, self.f_g = nets8x.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
         self.d_out, _ = nets8x.growing_disc(self.y_gp, self.x_disc, self.percentage, reuse=True, **dk)
         self.k2_ls = list(k2_ls) if k2_ls is not None else [1.0] * len(self.f_y)
+        # temporal discriminator (multipassGAN-8x.py:1158-1300; final growing stage, tensorResample advection)
+        self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
+        if use_tempo:
+            self.x_t = G.placeholder([None, cfg.n_input], name="x_t")
+            self.gen_ts = nets8x.growing_gen(self.x_t, self.percentage, cfg, reuse=True, train=True,
+                                             currentUpres=self.currentUpres)
+            tk = dict(cfg=cfg, n_t_channels=self.n_t, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
+            self.t_fake = G.placeholder([None, cfg.n_output * self.n_t], name="t_fake")
+            self.t_real = G.placeholder([None, cfg.n_output * self.n_t], name="t_real")
+            self.t_gp = G.placeholder([None, cfg.n_output * self.n_t], name="t_gp")
+            self.gen_s = nets8x.growing_disc_tempo(self.t_fake, self.percentage, reuse=False, **tk)
+            self.disc_s = nets8x.growing_disc_tempo(self.t_real, self.percentage, reuse=True, **tk)
+            self.t_out = nets8x.growing_disc_tempo(self.t_gp, self.percentage, reuse=True, **tk)
         self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, device=device)
         if use_wgan_gp:
-            self.sess.higher_order_scopes = ("spatial-disc",)
+            self.sess.higher_order_scopes = ("spatial-disc", "tempo-disc")
         self.g_var = self.sess.trainable("g_")
         self.d_var = self.sess.trainable("d_")
         self.opt_d = AdamTF(self.d_var, learning_rate, beta1, beta2, comm=comm)
         self.opt_g = AdamTF(self.g_var, learning_rate, beta1, beta2, comm=comm)
+        if use_tempo:
+            self.t_var = {n: p for n, p in self.sess.trainable("t_").items() if n.startswith("tempo-disc")}
+            self.opt_t = AdamTF(self.t_var, learning_rate, beta1, beta2, comm=comm)
         self.ema_decay = ema_decay
         self.ema = [p.detach().clone() for p in self.opt_g.params]
         self.rng = torch.Generator(device="cpu").manual_seed(seed)
@@ -900,23 +917,74 @@ class Trainer8x(object):
         L["gen_loss_complete"] = L["g_loss_d"] + L["l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
         return L
 
+    # ------------------------------------------------------------------ temporal branch
+    def _frames_as_channels(self, frames, y_pos):
+        th = self.cfg.tileSizeHigh
+        v = frames.reshape(-1, th, th, 1)
+        if self.adv_flag:
+            pos = torch.as_tensor(y_pos, dtype=torch.float32, device=v.device).reshape(-1, th, th, 2)
+            v = ResampleFn.apply(v, pos, self.clamping)
+        return v.reshape(-1, self.n_t, self.cfg.n_output).permute(0, 2, 1).reshape(-1, self.cfg.n_output * self.n_t)
+
+    def tempo_losses(self, batch_xts, batch_yts, batch_y_pos=None, percentage=3.0, lerp_factor=None, need_gp=True):
+        """t_disc_loss / g_loss_t of multipassGAN-8x.py:1216-1300 for [3B, .] coherent frame rows (final stage)"""
+        dev = self.sess.device
+        xts = torch.as_tensor(batch_xts, dtype=torch.float32, device=dev)
+        yts = torch.as_tensor(batch_yts, dtype=torch.float32, device=dev)
+        gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.percentage: percentage})[0]
+        fake = self._frames_as_channels(gen_ts, batch_y_pos)
+        real = self._frames_as_channels(yts, batch_y_pos)
+        gen_s, disc_s = self.sess.run([self.gen_s, self.disc_s], {self.t_fake: fake, self.t_real: real,
+                                                                   self.percentage: percentage})
+        L = {"t_loss_y": self._adv(disc_s, True), "t_loss_g": self._adv(gen_s, False)}
+        t_disc_loss = L["t_loss_y"] * self.weight_dld + L["t_loss_g"]
+        if self.use_wgan_gp and need_gp:
+            if lerp_factor is None:
+                lerp_factor = torch.rand((fake.shape[0], 1), generator=self.rng)
+            lf = torch.as_tensor(lerp_factor, dtype=torch.float32, device=dev).reshape(-1, 1)
+            y_gp = (lf * real + (1.0 - lf) * fake.detach()).requires_grad_(True)
+            t_out = self.sess.run([self.t_out], {self.t_gp: y_gp, self.percentage: percentage})[0]
+            (grads_t,) = torch.autograd.grad(t_out.mean(), y_gp, create_graph=True)
+            # [B, n_output, n_t]: the norm runs over the pixels of each frame (reduce_sum(axis=1), :1287)
+            gt = grads_t.reshape(-1, self.cfg.n_output, self.n_t)
+            norm = torch.sqrt(((gt + 1e-4) ** 2).sum(dim=1))
+            L["grad_penalty_t"] = (self.wgan_lambda * (norm - self.wgan_target) ** 2).mean()
+            L["epsilon_penalty_t"] = (disc_s ** 2).mean()
+            t_disc_loss = t_disc_loss + L["epsilon_penalty_t"] * self.wgan_epsilon + L["grad_penalty_t"]
+        L["t_disc_loss"] = t_disc_loss
+        L["g_loss_t"] = self._adv(gen_s, True)
+        return L
+
+    def tempo_disc_step(self, batch_xts, batch_yts, batch_y_pos=None, percentage=3.0, lerp_factor=None):
+        L = self.tempo_losses(batch_xts, batch_yts, batch_y_pos, percentage, lerp_factor)
+        grads = torch.autograd.grad(L["t_disc_loss"], self.opt_t.params, allow_unused=True)
+        self.opt_t.step(grads)
+        return L
+
     def disc_step(self, batch_xs, batch_ys, percentage=3.0, lerp_factor=None):
         L = self.losses(batch_xs, batch_ys, percentage, lerp_factor)
         grads = torch.autograd.grad(L["disc_loss"], self.opt_d.params, allow_unused=True)
         self.opt_d.step(grads)
         return L
 
-    def gen_step(self, batch_xs, batch_ys, percentage=3.0):
+    def gen_step(self, batch_xs, batch_ys, percentage=3.0, tempo=None):
         L = self.losses(batch_xs, batch_ys, percentage, need_gp=False)
+        if tempo is not None:
+            Lt = self.tempo_losses(tempo[0], tempo[1], tempo[2], percentage, need_gp=False)
+            L.update(Lt)
+            L["gen_loss_complete"] = L["gen_loss_complete"] + self.kt * Lt["g_loss_t"]        # :1302
         grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
         self.opt_g.step(grads)
         with torch.no_grad():       # MovingAverageOptimizer(…, 0.999): shadow += (1 - decay) * (var - shadow)
             torch._foreach_lerp_(self.ema, [p.detach() for p in self.opt_g.params], 1.0 - self.ema_decay)
         return L
 
-    def train_step(self, batch_xs, batch_ys, percentage=3.0, discRuns=1, genRuns=1):
+    def train_step(self, batch_xs, batch_ys, percentage=3.0, discRuns=1, genRuns=1, tempo=None):
         for _ in range(discRuns):
             Ld = self.disc_step(batch_xs, batch_ys, percentage)
+        if tempo is not None:
+            for _ in range(discRuns):
+                self.tempo_disc_step(tempo[0], tempo[1], tempo[2], percentage)
         for _ in range(genRuns):
-            Lg = self.gen_step(batch_xs, batch_ys, percentage)
+            Lg = self.gen_step(batch_xs, batch_ys, percentage, tempo)
         return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()

@@ -115,6 +115,53 @@ def growing_disc(p, high_nchw, low_density_np, percentage, up_res=8, current_upr
     return score, feats
 
 
+def growing_disc_tempo(p, x_nchw, percentage, up_res=8, current_upres=3):
+    """growing_disc_tempo (multipassGAN-8x.py:866-923), firstNNArch: [N,3,H,W] -> score"""
+    t = "tempo-disc/"
+    x = conv(p, t + "t_cfromDensity%d" % up_res, x_nchw)
+    in_high = x_nchw
+    pooled = None
+    for j in range(current_upres, 0, -1):
+        in_high = F.avg_pool2d(in_high, 2)
+        pooled, _, _ = grow_block_disc(p, t + "tBlock%d/" % (2 ** j), "t", x, 2 ** j)
+        old = conv(p, t + "t_cfromDensity%d" % (2 ** (j - 1)), in_high)
+        x = lerp(old, pooled, percentage - (j - 1))
+    flat = pooled.permute(0, 2, 3, 1).reshape(pooled.shape[0], -1)
+    w = p[t + "t_l61/weight"]
+    return flat @ (w * _ws(w, 1.0)) + p[t + "t_l61/bias"]
+
+
+def tempo_losses_8x(p, batch_xts, batch_yts, batch_y_pos, tile_low, channels, percentage=3.0, lerp_factor=None,
+                    wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True):
+    """t_disc_loss / g_loss_t (WGAN-GP) of multipassGAN-8x.py:1216-1300 at the final stage"""
+    from .train_ref import tensor_resample
+    th = tile_low * 8
+    xs = np.asarray(batch_xts, np.float32).reshape(-1, tile_low, tile_low, channels)
+    gen_ts = growing_gen(p, xs, percentage, first_nn_arch)                 # [3B,1,H,W]
+
+    def pack(frames_nhwc):
+        v = tensor_resample(frames_nhwc, batch_y_pos, True)
+        return v.reshape(-1, 3, th * th).permute(0, 2, 1)                  # [B, n_output, 3]
+
+    fake = pack(gen_ts.permute(0, 2, 3, 1))
+    real = pack(torch.tensor(np.asarray(batch_yts), dtype=DT).reshape(-1, th, th, 1))
+    to_img = lambda v: v.reshape(-1, th, th, 3).permute(0, 3, 1, 2)       # noqa: E731
+    gen_s = growing_disc_tempo(p, to_img(fake), percentage)
+    disc_s = growing_disc_tempo(p, to_img(real), percentage)
+    L = {}
+    t_disc_loss = (-disc_s).mean() * weight_dld + gen_s.mean()
+    if lerp_factor is not None:
+        lf = torch.tensor(np.asarray(lerp_factor), dtype=DT).reshape(-1, 1, 1)
+        y_gp = (lf * real + (1 - lf) * fake.detach()).requires_grad_(True)
+        t_out = growing_disc_tempo(p, to_img(y_gp), percentage)
+        (g,) = torch.autograd.grad(t_out.mean(), y_gp, create_graph=True)
+        norm = torch.sqrt(((g + 1e-4) ** 2).sum(dim=1))
+        t_disc_loss = t_disc_loss + (disc_s ** 2).mean() * wgan_epsilon + (wgan_lambda * (norm - wgan_target) ** 2).mean()
+    L["t_disc_loss"] = t_disc_loss
+    L["g_loss_t"] = (-gen_s).mean()
+    return L
+
+
 def losses_8x(p, batch_xs, batch_ys, tile_low, channels, percentage=3.0, lerp_factor=None, lambda_l1=1.0, lambda2=0.0,
               wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True):
     """WGAN-GP losses of multipassGAN-8x.py:1082-1142 at the final growing stage's tile size"""

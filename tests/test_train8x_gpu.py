@@ -107,3 +107,41 @@ def test_lsgan_variant_losses():
     gen, _ = TR8.growing_disc(p, gen_y, low, 3.0)
     want = 0.5 * ((disc - 1.0) ** 2).mean() + 0.5 * (gen ** 2).mean()
     assert abs(float(L["disc_loss"].detach()) - float(want)) < 2e-4 * max(abs(float(want)), 1e-2)
+
+
+def test_temporal_critic_losses_and_gradients():
+    """growing_disc_tempo on advected frame triples with its own gradient penalty; generator term"""
+    import contextlib
+    import io
+    import random
+    from mpgan_amd import tilecreator_t as tc
+    tile, C = 8, 4
+    rng = np.random.default_rng(41)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tiCr = tc.TileCreator(tileSizeLow=tile, simSizeLow=16, upres=8, dim=2, dim_t=3, densityMinimum=0.0,
+                              channelLayout_low="d,vx,vy,vz", channelLayout_high="d")
+        tiCr.addData(rng.random((4, 1, 16, 16, 12)).astype(np.float32), rng.random((4, 1, 128, 128, 3)).astype(np.float32))
+    random.seed(2)
+    xts, yts, ypos = tiCr.selectRandomTempoTiles(6, True, False, n_t=3, dt=0.5)
+    tr, p, xs, ys, lf = make(tile=tile, C=C, batch=2, use_tempo=True)
+    lf_t = rng.random((2, 1)).astype(np.float32)
+    L = tr.tempo_losses(xts, yts, ypos, 3.0, lf_t)
+    Lr = TR8.tempo_losses_8x(p, xts, yts, ypos, tile, C, 3.0, lf_t)
+    for k in ("t_disc_loss", "g_loss_t"):
+        a, b = float(L[k].detach()), float(Lr[k].detach())
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-2), (k, a, b)
+    gt = torch.autograd.grad(L["t_disc_loss"], tr.opt_t.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["g_loss_t"], tr.opt_g.params, allow_unused=True)
+    rt = {k: v for k, v in TR.grads(Lr["t_disc_loss"], p, "t_").items() if k.startswith("tempo-disc")}
+    rg = TR.grads(Lr["g_loss_t"], p, "g_")
+    assert sorted(rt) == tr.opt_t.names
+    for names, got, want in ((tr.opt_t.names, gt, rt), (tr.opt_g.names, gg, rg)):
+        for nme, g in zip(names, got):
+            w = want[nme]
+            gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
+            if np.abs(w).max() == 0.0:
+                assert np.abs(gnp).max() < 1e-7, nme
+                continue
+            assert rel(gnp, w) < 5e-3, (nme, rel(gnp, w))
+    d, g = tr.train_step(xs[:2], ys[:2], 3.0, tempo=(xts, yts, ypos))
+    assert np.isfinite(float(d)) and np.isfinite(float(g))
