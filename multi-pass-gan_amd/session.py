@@ -118,8 +118,11 @@ class Session(object):
         single = isinstance(fetches, G.Node)
         flist = [fetches] if single else list(fetches)
         feeds = {}
+        self._scalars = {}
         for k, v in (feed_dict or {}).items():
-            if isinstance(k, G.Node):
+            if isinstance(k, G.Scalar):
+                self._scalars[k.node] = float(v)          # e.g. `percentage` of the growing nets
+            elif isinstance(k, G.Node):
                 feeds[k] = torch.as_tensor(np.ascontiguousarray(v), dtype=torch.float32).to(self.device)
         outs = [self.run_device(f, feeds).cpu().numpy() for f in flist]
         return outs[0] if single else outs
@@ -519,6 +522,16 @@ class Session(object):
         if op == "avg_pool":
             x = n.inputs[0]
             return [x], lambda env: ops.avg_pool2(self._f32(env, x))
+        if op == "lerp":
+            from . import train_ops
+            t = n.attrs["t"]
+
+            def run_lerp(env, n=n, t=t):
+                tv = t.value(getattr(self, "_scalars", {})) if isinstance(t, G.Scalar) else float(t)
+                xin = None if n.attrs["zero_x"] else self._f32(env, n.inputs[0])
+                return train_ops.lerp(xin, self._f32(env, n.inputs[-1]), tv)
+
+            return list(n.inputs), run_lerp
         if op in ("conv2d", "bias_add", "batch_norm"):
             direct = self._match_direct(n, single_use)
             if direct is not None:

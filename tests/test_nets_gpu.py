@@ -168,3 +168,39 @@ def test_disc_binclass_forward(mpg, nch):
     for a, b in zip(got, ref):
         assert a.shape == b.shape
         assert rel_l2(a, b) < 1e-5, rel_l2(a, b)
+
+
+@pytest.mark.parametrize("percentage", [3.0, 1.6])
+def test_growing_disc_forward_inference_session(percentage):
+    """8x discriminator (row a9) through the inference Session (fused launches, fed `percentage`) vs the
+    float64 restatement"""
+    import torch
+    from mpgan_amd import graph as G
+    from mpgan_amd import nets8x
+    from mpgan_amd.session import Session, VariableStore
+    from oracle import train_ref as TR
+    from oracle import train_ref8x as TR8
+    cfg = nets8x.Cfg8x(tileSizeLow=8, upRes=8, n_inputChannels=6, start_fms=32, max_fms=32)
+    g = G.reset_default_graph()
+    per = G.scalar_placeholder("percentage")
+    x_low = G.placeholder([None, cfg.n_input])
+    y = G.placeholder([None, cfg.n_output])
+    score, feats = nets8x.growing_disc(y, x_low, per, cfg, train=False)
+    ps = ON.ParamSource(seed=17)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in g.variables.items()}
+    vs = VariableStore(DEV)
+    vs.load(params)
+    sess = Session(graph=g, variables=vs, device=DEV)
+    rng = np.random.default_rng(4)
+    xs = rng.random((3, cfg.n_input)).astype(np.float32)
+    ys = rng.random((3, cfg.n_output)).astype(np.float32)
+    got = sess.run([score] + feats, {x_low: xs, y: ys, per: percentage})
+    low = xs.reshape(-1, 8, 8, 6)[..., :1]
+    want_s, want_f = TR8.growing_disc(TR.to_params(params), torch.tensor(ys, dtype=torch.float64).reshape(-1, 1, 64, 64), low, percentage)
+    assert rel_l2(got[0], want_s.detach().numpy()) < 1e-4
+    for a, b in zip(got[1:], want_f):
+        bn = b.detach().permute(0, 2, 3, 1).numpy()
+        if np.abs(bn).max() == 0:
+            assert np.abs(a).max() == 0
+        else:
+            assert rel_l2(a, bn) < 1e-4
