@@ -139,16 +139,23 @@ __global__ void avg_pool2_kernel(const float* __restrict__ x, int n, int h, int 
     y[idx] = (base[0] + base[c] + base[(size_t)w * c] + base[(size_t)w * c + c]) * 0.25f;
 }
 
-// one wave per pixel group: each thread owns one pixel when c is small, else strides channels
-__global__ void pixel_norm_kernel(const float* __restrict__ x, size_t npix, int c, float eps, float* __restrict__ y) {
-    const size_t pix = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (pix >= npix) return;
-    const float* p = x + pix * c;
+// `lanes` (a power of two <= 64) consecutive lanes share one pixel and stride its channels, so a wave reads
+// contiguous memory; the sum of squares is folded with shuffles inside the lane group
+__global__ void pixel_norm_kernel(const float* __restrict__ x, size_t npix, int c, int lanes, float eps,
+                                  float* __restrict__ y) {
+    const size_t gid = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t pix = gid / lanes;
+    const int l = (int)(gid % lanes);
+    const bool ok = pix < npix;
+    const float* p = x + (ok ? pix : 0) * c;
     float ss = 0.f;
-    for (int i = 0; i < c; ++i) ss = fmaf(p[i], p[i], ss);
+    if (ok)
+        for (int i = l; i < c; i += lanes) ss = fmaf(p[i], p[i], ss);
+    for (int m = lanes >> 1; m > 0; m >>= 1) ss += __shfl_xor(ss, m);
+    if (!ok) return;
     const float sc = rsqrtf(ss / (float)c + eps);
     float* q = y + pix * c;
-    for (int i = 0; i < c; ++i) q[i] = p[i] * sc;
+    for (int i = l; i < c; i += lanes) q[i] = p[i] * sc;
 }
 
 __global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int act,
@@ -313,7 +320,10 @@ extern "C" int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, 
 extern "C" int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, int c, float eps, float* y) {
     MPG_REQUIRE(x && y, "mpg_pixel_norm: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_pixel_norm: bad shape");
-    hipLaunchKernelGGL(pixel_norm_kernel, dim3(grid_for(npix)), dim3(BLK), 0, (hipStream_t)stream, x, npix, c, eps, y);
+    int lanes = 1;
+    while (lanes * 2 <= c && lanes < 64) lanes <<= 1;
+    hipLaunchKernelGGL(pixel_norm_kernel, dim3(grid_for(npix * lanes)), dim3(BLK), 0, (hipStream_t)stream, x, npix, c, lanes,
+                       eps, y);
     MPG_LAUNCH_CHECK("pixel_norm_kernel");
 }
 

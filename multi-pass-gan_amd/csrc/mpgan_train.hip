@@ -262,18 +262,23 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     dx[idx] = dy[idx] * d;
 }
 
-// y = x * r, r = rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y))
+// y = x * r, r = rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)); `lanes` consecutive lanes per pixel
 __global__ void pixel_norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t npix, int c,
-                                      float eps, float* __restrict__ dx) {
-    const size_t p = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (p >= npix) return;
-    const float* xp = x + p * c;
-    const float* dp = dy + p * c;
+                                      int lanes, float eps, float* __restrict__ dx) {
+    const size_t gid = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t pix = gid / lanes;
+    const int l = (int)(gid % lanes);
+    const bool ok = pix < npix;
+    const float* xp = x + (ok ? pix : 0) * c;
+    const float* dp = dy + (ok ? pix : 0) * c;
     float ss = 0.f, dot = 0.f;
-    for (int i = 0; i < c; ++i) { ss = fmaf(xp[i], xp[i], ss); dot = fmaf(dp[i], xp[i], dot); }
+    if (ok)
+        for (int i = l; i < c; i += lanes) { ss = fmaf(xp[i], xp[i], ss); dot = fmaf(dp[i], xp[i], dot); }
+    for (int m = lanes >> 1; m > 0; m >>= 1) { ss += __shfl_xor(ss, m); dot += __shfl_xor(dot, m); }
+    if (!ok) return;
     const float r = rsqrtf(ss / c + eps);
-    const float k = dot * r * r / c;     // mean_c(dy*y) * r / x-scale
-    for (int i = 0; i < c; ++i) dx[p * c + i] = r * (dp[i] - xp[i] * k);
+    const float k = dot * r * r / c;
+    for (int i = l; i < c; i += lanes) dx[pix * c + i] = r * (dp[i] - xp[i] * k);
 }
 
 // nearest upsample by integer factors: dx[iy,ix] = sum of the fy x fx block of dy
@@ -580,8 +585,10 @@ extern "C" int mpg_pixel_norm_bwd(mpg_stream_t stream, const float* dy, const fl
                                   float* dx) {
     MPG_REQUIRE(dy && x && dx, "mpg_pixel_norm_bwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_pixel_norm_bwd: bad shape");
-    hipLaunchKernelGGL(pixel_norm_bwd_kernel, dim3(grid_for(npix)), dim3(BLK), 0, (hipStream_t)stream, dy, x, npix, c,
-                       eps, dx);
+    int lanes = 1;
+    while (lanes * 2 <= c && lanes < 64) lanes <<= 1;
+    hipLaunchKernelGGL(pixel_norm_bwd_kernel, dim3(grid_for(npix * lanes)), dim3(BLK), 0, (hipStream_t)stream, dy, x, npix,
+                       c, lanes, eps, dx);
     MPG_LAUNCH_CHECK("pixel_norm_bwd_kernel");
 }
 

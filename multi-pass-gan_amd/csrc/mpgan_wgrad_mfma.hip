@@ -38,7 +38,14 @@ __device__ __forceinline__ float pow2_scale(float amax) {
 __global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned int* __restrict__ out) {
     __shared__ float red[BLK];
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK) m = fmaxf(m, fabsf(x[i]));
+    const size_t n4 = ((((uintptr_t)x) & 15) == 0) ? n / 4 : 0;          // 16-byte loads over the aligned bulk
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n4; i += (size_t)gridDim.x * BLK) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * BLK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLK)
+        m = fmaxf(m, fabsf(x[i]));
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = BLK / 2; s > 0; s >>= 1) {
@@ -315,10 +322,9 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     if (e == hipSuccess) e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nx + BLK * 8 - 1) / (BLK * 8) > 1024 ? 1024 : (nx + BLK * 8 - 1) / (BLK * 8))),
-                       dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)((nd + BLK * 8 - 1) / (BLK * 8) > 1024 ? 1024 : (nd + BLK * 8 - 1) / (BLK * 8))),
-                       dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
+    auto am_grid = [](size_t n) { const size_t b = (n + BLK * 16 - 1) / (BLK * 16); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
+    hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
+    hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nd)), dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cin + 63) / 64), dim3(256), 0, s, x, h, w, cin, wp,
                        amax, xp);
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cout + 63) / 64), dim3(256), 0, s, dy, h, w, cout, wp,
