@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""8x progressive-growing training driver: the ``name value`` command line of the reference's
+GAN/multipassGAN-8x.py (params :30-158) as example_run_training.py issues it for the FIRST network
+(upsamplingMode 2: low-res slices in, 8x slices out).
+
+What is rebuilt (reference line numbers): the data path :196-345 (FluidDataLoader slices of three
+coherent frames with the add_adj_idcs neighbour channels, intermediate-resolution targets
+``density_low_%i_%04d.uni`` for the 2x / 4x stages, ``density_high_%04d.uni`` for 8x), the growing schedule
+:1885-1975 (stageIter iterations of fade-in + stageIter of stabilisation per stage, data re-loaded when a
+stage completes), the iteration :1990-2060 (spatial critic, temporal critic on advected triples, generator)
+through ``train.Trainer8x``, the polynomial learning-rate decay :995-1009 after 6 * stageIter iterations,
+checkpoints ``model_%04d.ckpt.npz`` and the moving-average weights ``model_ema_%04d.ckpt.npz`` :1804-1812.
+
+Not rebuilt: output mode (use multipassGAN-out.py), the second / third networks (upsamplingMode 1 / 3 with
+upsampledData), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
+scaling (lossScaling is accepted and ignored: the arithmetic is fp32-grade), PNG test images, TensorBoard.
+"""
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch  # noqa: E402
+
+import mpgan_amd  # noqa: E402,F401
+from mpgan_amd import checkpoint  # noqa: E402
+from mpgan_amd import fluiddataloader as FDL  # noqa: E402
+from mpgan_amd import paramhelpers as ph  # noqa: E402
+from mpgan_amd import tilecreator_t as tc  # noqa: E402
+
+P = {}
+for name, default in [
+        ("out", False), ("basePath", '../2ddata_gan/'), ("randSeed", 1), ("load_model_test", -1), ("load_model_no", -1),
+        ("simSize", 64), ("tileSize", 16), ("upRes", 4), ("packedSimPath", '/data/share/GANdata/2ddata_sim/'),
+        ("fromSim", 1000), ("toSim", -1), ("dataDim", 2), ("numOut", 200), ("saveOut", False), ("loadOut", -1),
+        ("img", True), ("gif", False), ("ref", False), ("frame_min", 0), ("genModel", 'gen_test'),
+        ("discModel", 'disc_test'), ("learningRate", 0.0002), ("decayLR", False), ("dropout", 1.0), ("dropoutOutput", 1.0),
+        ("adam_beta1", 0.5), ("adam_beta2", 0.999), ("weight_dld", 1.0), ("lambda", 1.0), ("lambda2", 0.0),
+        ("lambda_f", 1.0), ("lambda2_f", 1.0), ("lambda2_l1", 1.0), ("lambda2_l2", 1.0), ("lambda2_l3", 1.0),
+        ("lambda2_l4", 1.0), ("useTempoD", True), ("useTempoL2", False), ("lambda_t", 1.0), ("lambda_t_l2", 0.0),
+        ("batchSize", 128), ("batchSizeDisc", 128), ("batchSizeGen", 128), ("trainGAN", True),
+        ("trainingIterations", 100000), ("discRuns", 1), ("genRuns", 1), ("batchNorm", False), ("pixelNorm", True),
+        ("bnDecay", 0.999), ("useVelocities", 0), ("useVorticities", 0), ("useFlags", 0), ("useK_Eps_Turb", 0),
+        ("premadeTiles", 0), ("dataAugmentation", 0), ("minScale", 0.85), ("maxScale", 1.15), ("rot", 2),
+        ("transposeAxis", 0), ("minAngle", -90.0), ("maxAngle", 90.0), ("flip", 1), ("pretrain", 0), ("pretrainDisc", 0),
+        ("pretrainGen", 0), ("testPathStartNo", 0), ("testInterval", 100), ("numTests", 128), ("outputInterval", 100),
+        ("saveInterval", 200), ("alwaysSave", True), ("keepMax", 3), ("genTestImg", -1), ("note", ""),
+        ("data_fraction", 0.3), ("frame_max", 200), ("adv_flag", True), ("adv_mode", 1), ("change_velocity", False),
+        ("saveMetaData", 0), ("use_spatialdisc", True), ("velScale", 1.0), ("upsamplingMode", 2), ("upsampledData", False),
+        ("genUni", False), ("upsampleFirst", True), ("usePixelShuffle", False), ("addBicubicUpsample", False),
+        ("startingIter", 0), ("loadEmas", False), ("useVelInTDisc", False), ("upsampleMode", 1), ("lossScaling", False),
+        ("stageIter", 25000), ("decayIter", 25000), ("maxFms", 256), ("use_wgan_gp", False), ("use_res_net", False),
+        ("use_mb_stddev", False), ("use_LSGAN", False), ("startFms", 512), ("filterSize", 3), ("outNNTestNo", 17),
+        ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2)]:
+    P[name] = ph.getParam(name, default)
+ph.checkUnusedParams()
+
+
+def fail(msg):
+    print("ERROR: " + msg)
+    exit(1)
+
+
+if int(P["out"]) > 0:
+    fail("output mode of the 8x networks is GAN/multipassGAN-out.py")
+if int(P["upsamplingMode"]) != 2 or int(P["upsampledData"]) or int(P["dataDim"]) != 2:
+    fail("training is implemented for the first network (upsamplingMode 2, upsampledData 0, dataDim 2)")
+if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
+    fail("vorticity / flag / k-eps inputs and premade tiles are not supported")
+if int(P["batchNorm"]) or int(P["usePixelShuffle"]) or int(P["use_mb_stddev"]) or int(P["gDrop"]) or int(P["useVelInTDisc"]):
+    fail("batchNorm / usePixelShuffle / use_mb_stddev / gDrop / useVelInTDisc are 0 in the reference runs and not built")
+upRes = int(P["upRes"])
+if upRes != 8:
+    fail("the growing networks are built for upRes 8")
+kt, kt_l = float(P["lambda_t"]), float(P["lambda_t_l2"])
+useTempoD = kt > 1e-6                                                # 8x.py:191-199
+if kt_l > 1e-6:
+    fail("the l2 temporal loss (lambda_t_l2) is not built; use lambda_t")
+if useTempoD and int(P["adv_flag"]) and int(P["adv_mode"]):
+    fail("adv_mode 1 / 2 (GAN.advect) is not built; use adv_mode 0 (tensorResample)")
+
+basePath, packedSimPath = P["basePath"], P["packedSimPath"]
+simSizeLow, tileSizeLow = int(P["simSize"]), int(P["tileSize"])
+fromSim, toSim = int(P["fromSim"]), int(P["toSim"])
+toSim = fromSim if toSim == -1 else toSim
+frame_min, frame_max = int(P["frame_min"]), int(P["frame_max"])
+randSeed = int(P["randSeed"])
+useVelocities, add_adj_idcs = int(P["useVelocities"]) > 0, int(P["add_adj_idcs"]) > 0
+stageIter, decayIter, startingIter = int(P["stageIter"]), int(P["decayIter"]), int(P["startingIter"])
+trainingIterations = stageIter * 6 + decayIter                      # :160-161
+data_fraction, min_data_fraction = float(P["data_fraction"]), 0.08
+batch = int(P["batchSize"])
+aug = int(P["dataAugmentation"]) > 0
+device = "cuda:0"
+
+channelLayout_low, mfl, mfh = 'd', ["density"], ["density"]
+if useVelocities:
+    channelLayout_low += ',vx,vy,vz'
+    mfl = mfl + ["velocity"]
+if add_adj_idcs:
+    channelLayout_low += ',d,d'
+n_inputChannels = len(channelLayout_low.split(','))
+dirIDs = np.linspace(fromSim, toSim, (toSim - fromSim + 1), dtype='int16')
+mol = [o for o in range(3) for _ in mfl]
+moh = [o for o in range(3) for _ in mfh]
+stride = 3
+
+
+def load_stage(currentUpres, first):
+    """TileCreator + data of one growing stage (:290-345 at start-up, :1920-1960 at a stage change)"""
+    tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.002 if first else 0.01, channelLayout_high='d',
+                          simSizeLow=simSizeLow, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=currentUpres,
+                          premadeTiles=False)
+    high = "density_high_%04d.uni" if currentUpres == upRes else "density_low_%i" % currentUpres + "_%04d.uni"
+    off = 0 if first else stride * (int(round(math.log(currentUpres, 2))) - 1)
+    fl = FDL.FluidDataLoader(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
+                             add_adj_idcs=add_adj_idcs, conv_slices=True, conv_axis=0,
+                             select_random=0.4 if first else 1.0, density_threshold=0.005 if first else 0.002,
+                             axis_scaling_y=[1, 1, 1, 1], axis_scaling=[currentUpres, 1, 1, 1],
+                             filename="density_low_%04d.uni", oldNamingScheme=False, filename_y=high,
+                             filename_index_max=frame_max + off, filename_index_min=frame_min + off, indices=dirIDs,
+                             data_fraction=max(data_fraction * 2 / currentUpres, min_data_fraction) if first else data_fraction,
+                             multi_file_list=mfl * 3, multi_file_idxOff=mol, multi_file_list_y=mfh * 3, multi_file_idxOff_y=moh)
+    if aug:
+        tiCr.initDataAugmentation(rot=int(P["rot"]), minScale=float(P["minScale"]), maxScale=float(P["maxScale"]),
+                                  flip=int(P["flip"]))
+    x, y, _ = fl.get()
+    x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_inputChannels * 3)
+    y = y.reshape(-1, 1, simSizeLow * currentUpres, simSizeLow * currentUpres, 3)
+    tiCr.addData(x, y)
+    return tiCr
+
+
+currentUpres = min(2 ** (startingIter // (stageIter * 2) + 1), 8)   # :215
+tiCr = load_stage(currentUpres, True)
+print("Random seed: {}".format(randSeed))
+np.random.seed(randSeed)
+test_path, _ = ph.getNextTestPath(int(P["testPathStartNo"]), basePath)
+print("\nUsing parameters:\n" + ph.paramsToString())
+ph.writeParams(test_path + "params.json")
+
+from mpgan_amd.nets8x import Cfg8x  # noqa: E402
+from mpgan_amd.train import Trainer8x  # noqa: E402
+
+cfg = Cfg8x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_inputChannels, upsampling_mode=2,
+            upsampleMode=int(P["upsampleMode"]), filterSize=int(P["filterSize"]), start_fms=int(P["startFms"]),
+            max_fms=int(P["maxFms"]), first_nn_arch=int(P["firstNNArch"]) > 0, use_res_net=int(P["use_res_net"]) > 0,
+            pixel_norm=int(P["pixelNorm"]) > 0, addBicubicUpsample=int(P["addBicubicUpsample"]) > 0,
+            bn_decay=float(P["bnDecay"]))
+learning_rate = float(P["learningRate"])
+trainer = Trainer8x(cfg, device=device, learning_rate=learning_rate, beta1=float(P["adam_beta1"]),
+                    beta2=float(P["adam_beta2"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
+                    weight_dld=float(P["weight_dld"]), use_wgan_gp=int(P["use_wgan_gp"]) > 0,
+                    use_LSGAN=int(P["use_LSGAN"]) > 0, seed=randSeed, use_tempo=useTempoD, lambda_t=kt,
+                    adv_flag=int(P["adv_flag"]) > 0)
+if int(P["load_model_test"]) >= 0:
+    params = checkpoint.load(checkpoint.model_path(basePath, int(P["load_model_test"]), int(P["load_model_no"])))
+    with torch.no_grad():
+        for n_, t_ in trainer.sess.params.items():
+            if n_ in params:
+                t_.copy_(torch.as_tensor(params[n_], device=t_.device))
+    print("Model restored.")
+
+
+def getinput():
+    """:1497-1537 incl. the 1-in-20 empty-density batches"""
+    batch_xs, batch_ys = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
+    if not min(np.random.randint(0, 20), 1):
+        batch_xs[:, :, :, :, 0:1] = 0
+        if add_adj_idcs:
+            batch_xs[:, :, :, :, 4:6] = 0
+        batch_xs[:, :, :, :, 1:4] *= (1.0 + np.random.rand() * 1.5)
+        batch_ys[:, :, :, :, :] = 0
+    return np.reshape(batch_xs, (-1, cfg.n_input)), np.reshape(batch_ys, (batch, -1))
+
+
+def getTempoinput():
+    bx, by, bp = tiCr.selectRandomTempoTiles(batch, True, aug, 3, 0.5)
+    n = bx.shape[0]
+    return np.reshape(bx, [n, -1]), np.reshape(by, [n, -1]), np.reshape(bp, [n, -1])
+
+
+save_no = 0
+
+
+def saveModel():
+    global save_no
+    trainer.sess.sync_to_store()
+    allp = trainer.sess.vars.numpy()
+    checkpoint.save(test_path + 'model_%04d.ckpt' % save_no, allp)
+    ema = dict(allp)
+    for n_, e_ in zip(trainer.opt_g.names, trainer.ema):           # MovingAverageOptimizer.swapping_saver (:1366)
+        ema[n_] = e_.detach().cpu().numpy()
+    checkpoint.save(test_path + 'model_ema_%04d.ckpt' % save_no, ema)
+    print('Saved Model %04d.' % save_no)
+    save_no += 1
+
+
+def poly_decay(step):
+    """tf.train.polynomial_decay(lr, step, decayIter, lr * 0.05, power=1.1) (:1006-1009)"""
+    s = min(step, decayIter)
+    return (learning_rate - learning_rate * 0.05) * (1 - s / float(decayIter)) ** 1.1 + learning_rate * 0.05
+
+
+# growing schedule (:1885-1975)
+interpolate_Perc = True
+start_interpol = stageIter * int(math.floor(startingIter // (stageIter * 2))) * 2 + stageIter
+interpol_c = int(math.floor(startingIter // (stageIter * 2)) * stageIter)
+if (startingIter // stageIter) % 2 == 0:
+    interpol_c += (startingIter - interpol_c) % stageIter
+    interpol_c += stageIter
+else:
+    interpolate_Perc = False
+lrgs = 0
+discRuns, genRuns = int(P["discRuns"]), int(P["genRuns"])
+outputInterval, saveInterval = int(P["outputInterval"]), int(P["saveInterval"])
+decayLR = int(P["decayLR"]) > 0
+avg_d = avg_g = avg_l1 = 0.0
+t0 = time.time()
+print('\n*****TRAINING STARTED***** (stop with ctrl-c)\n')
+for it in range(startingIter, trainingIterations):
+    if it - start_interpol == 0:
+        interpolate_Perc = False
+    if it - start_interpol == stageIter and currentUpres < upRes:    # a stage is complete: next resolution, new data
+        saveModel()
+        currentUpres *= 2
+        start_interpol = it + stageIter
+        interpolate_Perc = True
+        tiCr = load_stage(currentUpres, False)
+        print("--------------------------NEW UPRES: %d--------------------------" % currentUpres)
+    if interpolate_Perc:
+        interpol_c += 1
+        currBlendPer = interpol_c / stageIter
+    else:
+        currBlendPer = int(round(interpol_c / stageIter))
+    currBlendPer = min(max(currBlendPer, 1.0), 3.0)
+    if it >= stageIter * 6 and decayLR:
+        lrgs += 1
+    lr = poly_decay(lrgs) if decayLR else learning_rate
+    for opt in [trainer.opt_d, trainer.opt_g] + ([trainer.opt_t] if useTempoD else []):
+        opt.lr = lr
+    for _ in range(discRuns):
+        bx, by = getinput()
+        avg_d += float(trainer.disc_step(bx, by, currBlendPer)["disc_loss"].detach())
+    tempo = None
+    if useTempoD:
+        for _ in range(discRuns):
+            tempo = getTempoinput()
+            trainer.tempo_disc_step(tempo[0], tempo[1], tempo[2], currBlendPer)
+    for _ in range(genRuns):
+        bx, by = getinput()
+        if useTempoD:
+            tempo = getTempoinput()
+        L = trainer.gen_step(bx, by, currBlendPer, tempo)
+        avg_g += float(L["g_loss_d"].detach())
+        avg_l1 += float(L["l1_loss"].detach())
+    if (it + 1) % outputInterval == 0:
+        k = float(outputInterval)
+        print('\nIteration {:05d}/{}, Cost:'.format(it + 1, trainingIterations))
+        print('\tdisc: loss: train_loss={:.6f}'.format(avg_d / (k * discRuns)))
+        print('\tgen: loss: train={:.6f} L1={:.6f}'.format(avg_g / (k * genRuns), avg_l1 / (k * genRuns)))
+        print('\t blending percentage: %f' % currBlendPer)
+        print('\t{} iterations took {:.2f} seconds.'.format(outputInterval, time.time() - t0))
+        avg_d = avg_g = avg_l1 = 0.0
+        t0 = time.time()
+    if (it + 1) % saveInterval == 0:
+        saveModel()
+saveModel()
+print('\n*****TRAINING FINISHED*****')
+print('Test path: %s' % test_path)

@@ -885,7 +885,7 @@ class Trainer8x(object):
         """-> dict of loss tensors (multipassGAN-8x.py:1082-1142); batch_ys at full tileSizeHigh resolution"""
         dev = self.sess.device
         xs = torch.as_tensor(batch_xs, dtype=torch.float32, device=dev)
-        ys = torch.as_tensor(batch_ys, dtype=torch.float32, device=dev)
+        ys = self._to_full_res(torch.as_tensor(batch_ys, dtype=torch.float32, device=dev))
         feeds = {self.x: xs, self.x_disc: xs, self.y_in: ys, self.percentage: percentage}
         out = self.sess.run([self.gen_y, self.disc, self.gen] + list(self.f_y) + list(self.f_g), feeds)
         nf = len(self.f_y)
@@ -917,13 +917,35 @@ class Trainer8x(object):
         L["gen_loss_complete"] = L["g_loss_d"] + L["l1_loss"] * self.k + L["disc_loss_layer"] * self.k2
         return L
 
+    def _to_full_res(self, ys):
+        """targets of an earlier growing stage come at tileSizeLow * 2^stage: nearest resize to tileSizeHigh
+        (tf.image.resize_images(..., method=1), multipassGAN-8x.py:1055-1058)"""
+        th = self.cfg.tileSizeHigh
+        if ys.shape[1] == th * th:
+            return ys
+        cur = int(round(math.sqrt(ys.shape[1])))
+        if cur * cur != ys.shape[1] or th % cur:
+            raise _lib.MpgError("targets of %d values per tile do not fit tileSizeHigh %d" % (ys.shape[1], th))
+        return ops.resize_nearest(ys.reshape(-1, cur, cur, 1).contiguous(), th, th).reshape(-1, th * th)
+
     # ------------------------------------------------------------------ temporal branch
     def _frames_as_channels(self, frames, y_pos):
+        """advection look-up at the CURRENT stage's resolution (the positions come at tileSizeLow * 2^stage):
+        generated frames are nearest-downsampled to it, resampled, and resized back (:1178-1200)"""
         th = self.cfg.tileSizeHigh
-        v = frames.reshape(-1, th, th, 1)
+        cur = int(round(math.sqrt(frames.shape[1])))
         if self.adv_flag:
-            pos = torch.as_tensor(y_pos, dtype=torch.float32, device=v.device).reshape(-1, th, th, 2)
-            v = ResampleFn.apply(v, pos, self.clamping)
+            pos = torch.as_tensor(y_pos, dtype=torch.float32, device=frames.device)
+            pc = int(round(math.sqrt(pos.shape[1] // 2)))
+            v = frames.reshape(-1, cur, cur, 1)
+            if cur != pc:                                   # generator output (full size) -> current size
+                k = cur // pc
+                v = v[:, ::k, ::k, :].contiguous()
+            v = ResampleFn.apply(v, pos.reshape(-1, pc, pc, 2), self.clamping)
+            if pc != th:
+                v = (ResizeNearest2Fn if self.use_wgan_gp else ResizeNearestFn).apply(v, th, th)
+        else:
+            v = self._to_full_res(frames).reshape(-1, th, th, 1)
         return v.reshape(-1, self.n_t, self.cfg.n_output).permute(0, 2, 1).reshape(-1, self.cfg.n_output * self.n_t)
 
     def tempo_losses(self, batch_xts, batch_yts, batch_y_pos=None, percentage=3.0, lerp_factor=None, need_gp=True):

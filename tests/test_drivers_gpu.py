@@ -132,3 +132,59 @@ def test_4x_training_driver(tmp_path, lambda_t):
                                 "upsampledData", 0, "randSeed", 42], str(tmp_path))
     h, v = uniio.readUni(str(d / "density_low_2x2_0000.uni"))
     assert v.shape == (64, 64, 64, 1) and np.isfinite(v).all()
+
+
+def test_8x_training_driver(tmp_path):
+    """example_run_training.py's first command (reduced sizes): three growing stages with their own targets,
+    WGAN-GP spatial + temporal critics, checkpoints + moving-average checkpoints under the TF names, and the
+    trained generator runs in multipassGAN-out.py"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import checkpoint, uniio
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, frames = 8, 11
+    d = tmp_path / "data" / "sim_1005"
+    d.mkdir(parents=True)
+    (tmp_path / "models").mkdir()
+    for f in range(frames):
+        v = synthetic_volume(sim, 4, f)
+        uniio.writeUni(str(d / ("density_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim), v[..., 0:1] + 0.05)
+        uniio.writeUni(str(d / ("velocity_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim, vec3=True), v[..., 1:4])
+        for up, nm in ((2, "density_low_2_%04d.uni"), (4, "density_low_4_%04d.uni"), (8, "density_high_%04d.uni")):
+            hi = synthetic_volume(sim * up, 1, 100 * up + f) + 0.05
+            uniio.writeUni(str(d / (nm % f)), uniio.make_header(sim * up, sim * up, sim * up), hi)
+    args = ["randSeed", 16131119, "upRes", 8, "use_res_net", 1, "batchNorm", 0, "pixelNorm", 1, "out", 0, "pretrain", 0,
+            "pretrainDisc", 0, "tileSize", 8, "simSize", sim, "use_LSGAN", 0, "use_wgan_gp", 1, "lambda", 1.0, "lambda2", 0.0,
+            "discRuns", 1, "genRuns", 1, "alwaysSave", 1, "fromSim", 1005, "toSim", 1005, "outputInterval", 2, "genTestImg", -1,
+            "dropout", 0.5, "dataDim", 2, "batchSize", 3, "useVelocities", 1, "useVorticities", 0, "useK_Eps_Turb", 0,
+            "useFlags", 0, "gif", 0, "genModel", "gen_resnet", "discModel", "disc_binclass",
+            "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/", "lambda_t", 1.0,
+            "lambda_t_l2", 0.0, "frame_max", 2, "frame_min", 0, "data_fraction", 1.0, "adv_flag", 1, "adv_mode", 0,
+            "dataAugmentation", 0, "premadeTiles", 0, "rot", 1, "minScale", 0.85, "maxScale", 1.15, "flip", 1, "decayLR", 1,
+            "adam_beta1", 0.0, "adam_beta2", 0.99, "learningRate", 0.0001, "lossScaling", 1, "stageIter", 2, "decayIter", 2,
+            "maxFms", 32, "startFms", 32, "filterSize", 3, "upsamplingMode", 2, "upsampledData", 0, "load_model_test", -1,
+            "load_model_no", -1, "firstNNArch", 1, "add_adj_idcs", 1, "usePixelShuffle", 0, "addBicubicUpsample", 1,
+            "startingIter", 0, "useVelInTDisc", 0, "upsampleMode", 1, "gpu", 0, "saveInterval", 100]
+    out = _run("multipassGAN-8x.py", args, str(tmp_path))
+    assert "TRAINING FINISHED" in out and "NEW UPRES: 4" in out and "NEW UPRES: 8" in out
+    assert "blending percentage: 3.000000" in out
+    test_dir = tmp_path / "models" / "test_0000"
+    last = checkpoint.load(str(test_dir / "model_0002.ckpt"))
+    ema = checkpoint.load(str(test_dir / "model_ema_0002.ckpt"))
+    first = checkpoint.load(str(test_dir / "model_0000.ckpt"))
+    wname = "generator/genBlock8/g_cA_first/weight"
+    assert wname in last and all(np.isfinite(v).all() for v in last.values())
+    assert not np.array_equal(first[wname], last[wname]) and not np.array_equal(ema[wname], last[wname])
+    assert "tempo-disc/tBlock8/t_cA8/weight" in last and "spatial-disc/d_l61/weight" in last
+    # the trained first network in output mode
+    (tmp_path / "models" / "test_0004").mkdir()
+    oargs = ["randSeed", 200, "upRes", 8, "pixelNorm", 1, "batchNorm", 0, "out", 1, "tileSize", sim, "simSize", sim,
+             "fromSim", 1005, "useVelocities", 1, "useVorticities", 0, "useK_Eps_Turb", 0, "useFlags", 0,
+             "genModel", "gen_resnet", "discModel", "disc_binclass", "basePath", str(tmp_path / "models") + "/",
+             "packedSimPath", str(tmp_path / "data") + "/", "frame_max", 1, "frame_min", 0, "velScale", 1.0, "genUni", 1,
+             "upsampleMode", 1, "usePixelShuffle", 0, "loadEmas", 0, "addBicubicUpsample", 1, "gpu", 0, "transposeAxis", 0,
+             "firstNNArch", 1, "load_model_test_1", 0, "load_model_no_1", 2, "use_res_net1", 1, "add_adj_idcs1", 1,
+             "startFms1", 32, "maxFms1", 32, "filterSize1", 3, "load_model_test_2", -1, "load_model_no_2", -1,
+             "use_res_net2", 1, "add_adj_idcs2", 0, "startFms2", 192, "maxFms2", 192, "filterSize2", 5,
+             "load_model_test_3", -1, "load_model_no_3", -1, "use_res_net3", 0, "add_adj_idcs3", 0, "startFms3", 192,
+             "maxFms3", 96, "filterSize3", 5]
+    _run("multipassGAN-out.py", oargs, str(tmp_path))
