@@ -25,4 +25,9 @@ Pinning status
   it restates TF 1.x semantics from their published definition and is
   cross-checked against an independent PyTorch-CPU implementation
   (``oracle/torch_ref.py``) and authored known-answer tests.
+* The training graphs (``oracle/train_ref.py``: 4x GAN step, temporal discriminator,
+  ``tensorResample``, TF-flavoured Adam; ``oracle/train_ref8x.py``: progressive-growing nets,
+  WGAN-GP) are float64 PyTorch-autograd restatements, **parity unpinned** for the same reason;
+  their gradients are checked against central finite differences and ``tensorResample`` against a
+  scalar loop (``tests/test_oracle.py``).
 """
