@@ -103,6 +103,10 @@ struct WgArgs {
     float wscale;
 };
 
+// prefetch registers for the x piece: 10 units (a 64-pixel chunk of 128 channels, hi + lo) where the
+// accumulators leave room, else 6 (32-pixel chunks)
+constexpr int x_units(int kw, int cotw) { return kw * cotw > 12 ? 6 : 10; }
+
 template <int KW, int COTW, int PREC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
     // global -> LDS copy plan: 16-byte units; unit -> (row = channel*nplane + plane, offset)
     const int xupr = (a.chunk + 16) / 8, dupr = a.chunk / 8;          // units per row
     const int xunits = xch * nplane * xupr, dunits = dch * nplane * dupr;
-    constexpr int XU = 6, DU = 4;                                      // units per thread
+    constexpr int XU = x_units(KW, COTW), DU = 4;                      // 16-byte units per thread and chunk
     u32x4 xreg[XU], dreg[DU];
 
     const int total_rows = a.n * a.h;
@@ -353,9 +357,10 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
             if (cotw == 3) cotw = 4;
             const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
             a.ks = 4 / (a.cit * a.cog);                           // waves left over split the 16-pixel k-steps of a chunk
-            a.chunk = 32 * a.ks;
-            // short rows, and at most 6 / 4 16-byte units per thread in the copy plan
-            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8) > 6 * 256 ||
+            a.chunk = 32 * a.ks < 64 ? 64 : 32 * a.ks;            // fewer barriers per pixel with 64-pixel chunks
+            const int xu = x_units(kw, cotw);
+            // short rows, and at most xu / 4 16-byte units per thread in the copy plan
+            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8) > xu * 256 ||
                                     a.cog * cotw * 32 * npl * (a.chunk / 8) > 4 * 256))
                 a.chunk /= 2;
             if (a.chunk / 16 < a.ks) a.ks = a.chunk / 16;         // the other waves idle (tiny layers)
@@ -363,7 +368,7 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
             a.drowb = a.chunk * 2 + 16;
             const size_t lds = 2 * ((size_t)a.cit * 32 * npl * a.xrowb + (size_t)a.cog * cotw * 32 * npl * a.drowb);
             MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_wgrad_mfma: LDS plan %zu bytes", lds);
-            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8) <= 6 * 256 && a.cog * cotw * 32 * npl * (a.chunk / 8) <= 4 * 256,
+            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8) <= xu * 256 && a.cog * cotw * 32 * npl * (a.chunk / 8) <= 4 * 256,
                         "mpg_conv2d_wgrad_mfma: copy plan");
             const int rows = n * h;
             int want = 1024 / kh;
