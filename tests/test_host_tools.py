@@ -118,3 +118,33 @@ def test_paramhelpers(mpg, tmp_path, capsys):
     assert (no, no2) == (0, 1) and os.path.isdir(p) and p2.endswith("out_0001-0002_0001/")
     ph.writeParams(str(tmp_path / "params.json"))
     assert ph.readParams(str(tmp_path / "params.json"))["upres"] == "8"
+
+
+def test_tf_saver_v2_bundle_round_trip(tmp_path):
+    """tf_checkpoint: the restated tensor-bundle format (sorted string table index + raw data) round trips,
+    several index blocks, prefix-compressed keys, scalars; checkpoint.load falls back to it.  No TensorFlow-written
+    file is available to pin the reader against (parity unpinned)."""
+    from mpgan_amd import checkpoint, tf_checkpoint as T
+    rng = np.random.default_rng(0)
+    d = {"generator/g_cA0/weight": rng.standard_normal((5, 5, 1, 2)).astype(np.float32),
+         "generator/g_cA0/bias": np.full(2, 0.1, np.float32), "global_step": np.array(7, np.int64),
+         "generator/g_cB1/weight": rng.standard_normal((5, 5, 16, 24)).astype(np.float32),
+         "beta1_power": np.array(0.5, np.float32), "d64": rng.standard_normal(3)}
+    for i in range(300):
+        d["generator/genBlock%d/g_cA_first/weight/ExponentialMovingAverage" % i] = rng.standard_normal((3, i % 5 + 1)).astype(np.float32)
+    prefix = str(tmp_path / "test_0001" / "model_0002.ckpt")
+    T.write_checkpoint(prefix, d, block_size=1024)
+    r = T.read_checkpoint(prefix)
+    assert sorted(r) == sorted(d)
+    for k in d:
+        assert r[k].dtype == d[k].dtype and r[k].shape == d[k].shape and np.array_equal(r[k], d[k]), k
+    # index structure: footer magic, more than one data block
+    raw = open(prefix + ".index", "rb").read()
+    assert int.from_bytes(raw[-8:], "little") == T.MAGIC
+    assert T._mask(T._crc32c(b"123456789")) == (((0xe3069283 >> 15) | (0xe3069283 << 17)) + 0xa282ead8) & 0xffffffff
+    loaded = checkpoint.load(prefix)                   # no .npz next to it: the TF reader is used, float32 only
+    assert "global_step" not in loaded and np.array_equal(loaded["generator/g_cA0/weight"], d["generator/g_cA0/weight"])
+    with pytest.raises(T.CheckpointFormatError):
+        bad = tmp_path / "bad.ckpt.index"
+        bad.write_bytes(b"\\0" * 64)
+        T.read_index(str(bad))
