@@ -158,6 +158,11 @@ int mpg_resize_bicubic(mpg_stream_t stream, const float* x, int n, int h, int w,
 int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y);
 /* GAN.pixel_norm standalone (GAN.py:472-474) */
 int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, int c, float eps, float* y);
+/* GAN.minibatch_stddev_layer (GAN.py:476-488): y[n,h,w,c+1] = concat(x, s[n % M]) with s[m] the mean over
+ * (h,w,c) of the standard deviation over the G = min(group_size, n) members {g*M + m} of group m, M = n / G.
+ * stat: M floats of scratch. */
+int mpg_minibatch_stddev(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int group_size,
+                         float* stat, float* y);
 /* y = act(a + b) elementwise (tf.nn.relu(tf.add(..)), multipassGAN-4x.py:523); b may be NULL */
 int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak, float* y);
 

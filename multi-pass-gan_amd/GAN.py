@@ -145,7 +145,8 @@ class GAN(object):
 
     # GAN.py:476-488
     def minibatch_stddev_layer(self, x, group_size=4):
-        raise NotImplementedError("minibatch_stddev_layer: off in every reference run (use_mb_stddev 0, multipassGAN-8x.py:149)")
+        self.layer = G.minibatch_stddev(x, group_size)
+        return self.layer
 
     # GAN.py:501-523: kb.resize_images == nearest replication by integer factors
     def max_depool(self, in_layer=None, depth_factor=2, height_factor=2, width_factor=2):

@@ -158,6 +158,44 @@ __global__ void pixel_norm_kernel(const float* __restrict__ x, size_t npix, int 
     for (int i = l; i < c; i += lanes) q[i] = p[i] * sc;
 }
 
+// GAN.minibatch_stddev_layer (GAN.py:476-488): batch index n = g * M + m (G groups members, M groups);
+// stat[m] = mean over (h, w, c) of sqrt(var over g + 1e-8).  Pass 1 accumulates the per-m sums.
+__global__ __launch_bounds__(256) void mbstd_stat_kernel(const float* __restrict__ x, int g, int m, size_t hwc,
+                                                         float* __restrict__ stat) {
+    __shared__ float red[BLK];
+    const int mi = blockIdx.y;
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < hwc; i += (size_t)gridDim.x * BLK) {
+        float mean = 0.f;
+        for (int k = 0; k < g; ++k) mean += x[((size_t)k * m + mi) * hwc + i];
+        mean /= (float)g;
+        float var = 0.f;
+        for (int k = 0; k < g; ++k) {
+            const float d = x[((size_t)k * m + mi) * hwc + i] - mean;
+            var = fmaf(d, d, var);
+        }
+        s += sqrtf(var / (float)g + 1e-8f);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(stat + mi, red[0]);
+}
+
+// pass 2: y[n, p, 0..c-1] = x, y[n, p, c] = stat[n % m] / hwc
+__global__ void mbstd_concat_kernel(const float* __restrict__ x, const float* __restrict__ stat, int m, size_t npix_per,
+                                    int c, size_t total, float inv_hwc, float* __restrict__ y) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % (c + 1);
+    const size_t pix = idx / (c + 1);
+    const int n = (int)(pix / npix_per);
+    y[idx] = ch < c ? x[pix * c + ch] : stat[n % m] * inv_hwc;
+}
+
 __global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int act,
                                float leak, float* __restrict__ y) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
@@ -325,6 +363,26 @@ extern "C" int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, 
     hipLaunchKernelGGL(pixel_norm_kernel, dim3(grid_for(npix * lanes)), dim3(BLK), 0, (hipStream_t)stream, x, npix, c, lanes,
                        eps, y);
     MPG_LAUNCH_CHECK("pixel_norm_kernel");
+}
+
+extern "C" int mpg_minibatch_stddev(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int group_size,
+                                    float* stat, float* y) {
+    MPG_REQUIRE(x && stat && y, "mpg_minibatch_stddev: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && group_size >= 1, "mpg_minibatch_stddev: bad shape");
+    const int g = group_size < n ? group_size : n;
+    MPG_REQUIRE(n % g == 0, "mpg_minibatch_stddev: batch %d is not divisible by the group size %d", n, g);
+    const int m = n / g;
+    const size_t hwc = (size_t)h * w * c;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = mpg::zero_async(stat, (size_t)m * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_minibatch_stddev: zero");
+    unsigned bx = (unsigned)((hwc + BLK * 4 - 1) / (BLK * 4));
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(mbstd_stat_kernel, dim3(bx, m), dim3(BLK), 0, s, x, g, m, hwc, stat);
+    const size_t total = (size_t)n * h * w * (c + 1);
+    hipLaunchKernelGGL(mbstd_concat_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, stat, m, (size_t)h * w, c, total,
+                       1.f / (float)hwc, y);
+    MPG_LAUNCH_CHECK("mbstd kernels");
 }
 
 extern "C" int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak,

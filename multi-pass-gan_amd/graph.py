@@ -238,6 +238,11 @@ def pixel_norm(x, epsilon=1e-8):
     return Node("pixel_norm", [x], shape=x.shape, eps=float(epsilon))
 
 
+def minibatch_stddev(x, group_size=4):
+    """GAN.minibatch_stddev_layer (GAN.py:476-488)"""
+    return Node("minibatch_stddev", [x], shape=(x.shape[0], x.shape[1], x.shape[2], x.shape[3] + 1), group_size=int(group_size))
+
+
 def resize_images(x, size, method=0):
     """tf.image.resize_images(x, [oh, ow], method) with TF1 legacy coordinates."""
     oh, ow = int(size[0]), int(size[1])

@@ -32,8 +32,6 @@ class Cfg8x(object):
         self.bn_decay = bn_decay
         if upsampling_mode not in (1, 2, 3):
             raise NotImplementedError("upsampling_mode %d (only 1, 2, 3 are used by the example runs)" % upsampling_mode)
-        if use_mb_stddev:
-            raise NotImplementedError("use_mb_stddev is 0 in every reference run (multipassGAN-8x.py:149)")
         self.n_input = (tileSizeLow ** 2 if upsampling_mode == 2 else self.tileSizeHigh ** 2) * n_inputChannels
         self.n_output = self.tileSizeHigh ** 2
 
@@ -171,6 +169,8 @@ def growing_disc(in_high_, in_low_, percentage, cfg, reuse=False, use_batch_norm
                 x_ = tf.reshape(lerp(_oldDens, x_, percentage - (j - 1)), shape=[-1, size, size, fromDensFms])
             feature_layers.append(lerp(None, x1, percentage - (j - 1)))
             feature_layers.append(lerp(None, x2, percentage - (j - 1)))
+        if c.use_mb_stddev:
+            x_ = gan.minibatch_stddev_layer(x_)
         filter = [c.filterSize, c.filterSize]
         if not c.first_nn_arch:
             x1, _ = gan.convolutional_layer(32, filter, lrelu, stride=[1], name="d_cA%d" % (1), in_layer=x_,
@@ -211,6 +211,8 @@ def growing_disc_tempo(in_high_, percentage, cfg, n_t_channels=3, reuse=True, us
             with tf.variable_scope("blend%i" % j, reuse=reuse):
                 size = c.tileSizeLow * (2 ** (j - 1)) if c.upsampling_mode == 2 else c.tileSizeHigh
                 x = tf.reshape(lerp(_oldDens, x, percentage - (j - 1)), shape=[-1, size, size, fromDensFms])
+        if c.use_mb_stddev:
+            x = gan.minibatch_stddev_layer(x, 1)
         filter = [c.filterSize, c.filterSize]
         if not c.first_nn_arch:
             x1, _ = gan.convolutional_layer(32, filter, lrelu, stride=[1], name="t_cA%d" % (1), in_layer=x, reuse=reuse,

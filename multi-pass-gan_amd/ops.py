@@ -276,6 +276,18 @@ def pixel_norm(x, eps=1e-8):
     return y
 
 
+def minibatch_stddev(x, group_size=4):
+    """GAN.minibatch_stddev_layer (GAN.py:476-488): [N,H,W,C] -> [N,H,W,C+1]"""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    g = min(group_size, n)
+    stat = torch.empty((n // g,), dtype=torch.float32, device=x.device)
+    y = torch.empty((n, h, w, c + 1), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_minibatch_stddev(_stream(), _ptr(x), n, h, w, c, group_size, _ptr(stat), _ptr(y)), "mpg_minibatch_stddev")
+    return y
+
+
 def add_act(a, b=None, act=None, leak=0.2):
     lib = _lib.load()
     a = _dev(a, "a")

@@ -533,6 +533,11 @@ class TrainSession(object):
             x = None if n.attrs["zero_x"] else ev(n.inputs[0])
             y = ev(n.inputs[-1])
             return (Lerp2Fn if self._higher(n) else LerpFn).apply(x, y, t)
+        if op == "minibatch_stddev":
+            x = ev(n.inputs[0])
+            if x.requires_grad:
+                raise NotImplementedError("gradient of minibatch_stddev_layer (use_mb_stddev is 0 in every reference run)")
+            return ops.minibatch_stddev(x.contiguous(), n.attrs["group_size"])
         if op == "resize":
             x = ev(n.inputs[0])
             if n.attrs["method"] == 1:

@@ -327,6 +327,16 @@ def test_pool_norm_add(gpu_ops):
     assert rel_l2(gpu_ops.add_act(_t(x), None, "lrelu").cpu().numpy(), O.lrelu(x)) < 1e-6
 
 
+@pytest.mark.parametrize("n,group", [(8, 4), (3, 4), (6, 2), (4, 1)])
+def test_minibatch_stddev(gpu_ops, n, group):
+    """GAN.minibatch_stddev_layer (GAN.py:476-488): the extra feature map of the group statistics"""
+    x = _rng(41 + n).standard_normal((n, 6, 10, 5)).astype(np.float32)
+    y = gpu_ops.minibatch_stddev(_t(x), group).cpu().numpy()
+    ref = O.minibatch_stddev(x, group)
+    assert y.shape == (n, 6, 10, 6) and np.array_equal(y[..., :5], x)
+    assert np.allclose(y[..., 5], ref[..., 5], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("axis", [0, 1, 2])
 @pytest.mark.parametrize("factor", [4, 8])
 def test_axis_zoom_matches_scipy(gpu_ops, axis, factor):
