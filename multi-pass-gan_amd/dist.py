@@ -39,7 +39,10 @@ class Comm(object):
             raise ValueError("slab has %d slices, expected %d" % (local.shape[0], per))
         local = local.contiguous()
         full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
+        if local.is_cuda:
+            dist.all_gather_into_tensor(full, local, group=self.group)
+        else:
+            dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
         return full
 
     def all_gather_slabs_start(self, local, total):
@@ -52,8 +55,12 @@ class Comm(object):
             raise ValueError("slab has %d slices, expected %d" % (local.shape[0], per))
         local = local.contiguous()
         full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        work = dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group,
-                               async_op=True)
+        if local.is_cuda:
+            # RCCL: one flat receive buffer (the slabs are contiguous along the slice axis), no staging copies
+            work = dist.all_gather_into_tensor(full, local, group=self.group, async_op=True)
+        else:
+            work = dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group,
+                                   async_op=True)
         return _Gathered(full, work, keep=local)
 
     def all_reduce_mean(self, flat):
