@@ -113,6 +113,9 @@ typedef struct mpg_conv_desc {
     void*   y_g8c;            /* G8 (MPG_G8_F8C) or NULL; at least one of the three outputs */
     int32_t prec;             /* MPG_PREC_* */
     int32_t reserved;         /* must be 0 */
+    const float* in_amax;     /* NULL, or device pointer to the absolute maximum the segment inputs were scaled by
+                               * (mpg_f32_to_g8_scaled): the sum is divided by the same power of two before bias
+                               * and activation.  Used for gradients, whose magnitude is below the fp16 normal range. */
 } mpg_conv_desc;
 
 /* bytes of the packed weight image of one segment. */
@@ -130,6 +133,12 @@ int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int 
  * so that max|w| * 2^w_exp <= 448 (the e4m3 range), e.g. floor(log2(224 / max|w|)). */
 
 int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* desc);
+
+/* out[0] = max |x_i| (device float).  mpg_f32_to_g8_scaled converts x * 2^k with 2^k = the power of two that brings
+ * that maximum into [2^8, 2^9); a convolution over such an input takes the same pointer in desc.in_amax. */
+int mpg_absmax(mpg_stream_t stream, const float* x, size_t n, float* out);
+int mpg_f32_to_g8_scaled(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
+                         int flavour, const float* amax, void* out);
 
 /* Plain fp32 direct convolution on the vector ALUs, any stride / kernel /
  * channel count (tf.nn.conv2d SAME, GAN.py:686-691; used for the strided
@@ -208,7 +217,8 @@ int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, i
 size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout);
 int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
                           const float* dy, int cout, int kh, int kw, float wscale, int prec,
-                          void* workspace, size_t workspace_bytes, float* dw);
+                          void* workspace, size_t workspace_bytes, const float* dy_amax, float* dw);
+/* dy_amax: NULL, or a device float holding max |dy| already computed with mpg_absmax */
 /* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
  * convs, multipassGAN-4x.py:607-614).  The filter is passed with its channel axes swapped,
  * w_hwoi[kh,kw,cout,cin].  Stride-1 filters can instead run mpg_conv2d_fused on dy with the

@@ -65,6 +65,7 @@ class ConvDesc(ctypes.Structure):
         ("y_g8c", ctypes.c_void_p),
         ("prec", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("in_amax", ctypes.c_void_p),
     ]
 
 
@@ -80,6 +81,8 @@ PROTOTYPES = {
     "mpg_device_info": (_I, [ctypes.POINTER(_I), ctypes.c_char_p, _I]),
     "mpg_g8_bytes": (_Z, [_I, _I, _I, _I]),
     "mpg_f32_to_g8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mpg_f32_to_g8_scaled": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mpg_absmax": (_I, [_P, _P, _Z, _P]),
     "mpg_g8_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I]),
     "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _Z]),
@@ -99,7 +102,7 @@ PROTOTYPES = {
     # training step
     "mpg_conv2d_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_conv2d_wgrad_mfma_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
-    "mpg_conv2d_wgrad_mfma": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _Z, _P]),
+    "mpg_conv2d_wgrad_mfma": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _Z, _P, _P]),
     "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_fc_forward": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _F, _P]),
     "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),

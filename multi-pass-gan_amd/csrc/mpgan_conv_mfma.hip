@@ -58,6 +58,7 @@ struct ConvArgs {
     float* y;             // fp32 NHWC output or null
     char* y_g8;           // G8 output (planes hi16, lo16) or null
     char* y_g8c;          // G8 output in the F16F8 flavour (planes hi16, {hi8 | lo8}) or null
+    const float* in_amax; // inputs were multiplied by pow2_scale(*in_amax): the accumulators are divided by it
     const char* zeros;    // >= 16 zero bytes (source of out-of-image pixels)
     int img_bytes;        // bytes of one LDS image buffer (max over segments)
     int tiles_x, tiles_y;
@@ -131,6 +132,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
     constexpr int ROWF = NT * 32 + 4;
     float* stg = reinterpret_cast<float*>(smem + TAPOFF_BYTES) + wave * (32 * ROWF);
     const int cg_out = (a.cout + 7) >> 3;
+    const float unscale = a.in_amax != nullptr ? 1.f / mpg::pow2_scale(*a.in_amax) : 1.f;
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int py = y0 + PT * wave + pt;
@@ -148,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = mpg::apply_act(acc[pt][nt][4 * q4 + i] + b4[i], a.act, a.leak);
+                    float v = mpg::apply_act(acc[pt][nt][4 * q4 + i] * unscale + b4[i], a.act, a.leak);
                     if (co0 + i >= a.cout) v = 0.f;
                     acc[pt][nt][4 * q4 + i] = v;
                     ss += v * v;
@@ -676,6 +678,7 @@ struct SmallArgs {
     int n, h, w, cout, nseg, f8c_in;
     SmallSeg seg[MPG_MAX_SEG];
     const float* bias;
+    const float* in_amax;
     int act;
     float leak;
     float* y;
@@ -719,7 +722,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
     const int x = x0 + tx, y = y0 + ty;
     float acc[8];          // COUT live accumulators (cout rounded up to 1, 2, 4, 8); the rest stays zero
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (a.bias != nullptr && j < a.cout) ? a.bias[j] : 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     for (int s = 0; s < a.nseg; ++s) {
         const SmallSeg& g = a.seg[s];
         const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
@@ -776,8 +779,10 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
         }
     }
     if (x >= a.w || y >= a.h) return;
+    const float unscale = a.in_amax != nullptr ? 1.f / mpg::pow2_scale(*a.in_amax) : 1.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = j < a.cout ? mpg::apply_act(acc[j], a.act, a.leak) : 0.f;
+    for (int j = 0; j < 8; ++j)
+        acc[j] = j < a.cout ? mpg::apply_act(acc[j] * unscale + (a.bias != nullptr ? a.bias[j] : 0.f), a.act, a.leak) : 0.f;
     const size_t plane_px = (size_t)a.h * a.w;
     const size_t pix = (size_t)y * a.w + x;
     if (a.y != nullptr) {
@@ -809,7 +814,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
 
 // fp32 NHWC -> G8
 __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off, int cin,
-                                 int f8c, _Float16* __restrict__ out) {
+                                 int f8c, const float* __restrict__ amax, _Float16* __restrict__ out) {
+    const float scale = amax != nullptr ? mpg::pow2_scale(*amax) : 1.f;
     const int cg_n = (cin + 7) >> 3;
     const size_t plane_px = (size_t)h * w;
     const size_t total = (size_t)n * cg_n * plane_px;
@@ -824,7 +830,7 @@ __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int 
     float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = (cg * 8 + j < cin) ? src[j] : 0.f;
+        const float v = (cg * 8 + j < cin) ? src[j] * scale : 0.f;
         vv[j] = v;
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
@@ -964,15 +970,20 @@ extern "C" size_t mpg_g8_bytes(int n, int h, int w, int c) {
     return (size_t)n * ((c + 7) / 8) * 2 * h * w * 16;
 }
 
-extern "C" int mpg_f32_to_g8(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
-                             int flavour, void* out) {
+extern "C" int mpg_f32_to_g8_scaled(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
+                                    int flavour, const float* amax, void* out) {
     MPG_REQUIRE(flavour == MPG_G8_F16 || flavour == MPG_G8_F8C, "mpg_f32_to_g8: bad flavour %d", flavour);
     MPG_REQUIRE(x && out, "mpg_f32_to_g8: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && c_off >= 0 && cin >= 1 && c_off + cin <= c, "mpg_f32_to_g8: bad shape");
     const size_t total = (size_t)n * ((cin + 7) / 8) * h * w;
     hipLaunchKernelGGL(f32_to_g8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, h,
-                       w, c, c_off, cin, flavour == MPG_G8_F8C ? 1 : 0, (_Float16*)out);
+                       w, c, c_off, cin, flavour == MPG_G8_F8C ? 1 : 0, amax, (_Float16*)out);
     MPG_LAUNCH_CHECK("f32_to_g8_kernel");
+}
+
+extern "C" int mpg_f32_to_g8(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
+                             int flavour, void* out) {
+    return mpg_f32_to_g8_scaled(stream, x, n, h, w, c, c_off, cin, flavour, nullptr, out);
 }
 
 extern "C" int mpg_g8_to_f32(mpg_stream_t stream, const void* g8, int n, int h, int w, int c, float* y) {
@@ -1084,7 +1095,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
                 o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2; o.cin = g.cin;
             }
             for (int s = d->nseg; s < MPG_MAX_SEG; ++s) sa.seg[s] = sa.seg[0];
-            sa.bias = d->bias; sa.act = d->act; sa.leak = d->leak;
+            sa.bias = d->bias; sa.in_amax = d->in_amax; sa.act = d->act; sa.leak = d->leak;
             sa.y = d->y; sa.y_g8 = (char*)d->y_g8; sa.y_g8c = (char*)d->y_g8c;
             MPG_REQUIRE((((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0, "mpg_conv2d_fused: misaligned output");
             const size_t total = (size_t)d->n * d->h * d->w;
@@ -1140,7 +1151,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         max_img = ss.img_bytes > max_img ? ss.img_bytes : max_img;
     }
     for (int s = d->nseg; s < MPG_MAX_SEG; ++s) a.seg[s] = a.seg[0];
-    a.bias = d->bias; a.act = d->act; a.leak = d->leak; a.pn = d->pixel_norm; a.pn_eps = d->pn_eps;
+    a.bias = d->bias; a.in_amax = d->in_amax; a.act = d->act; a.leak = d->leak; a.pn = d->pixel_norm; a.pn_eps = d->pn_eps;
     a.post_add = d->post_add; a.pa_stride = d->post_add_stride; a.pa_coff = d->post_add_coff;
     MPG_REQUIRE(!d->post_add || d->post_add_coff + d->cout <= d->post_add_stride, "mpg_conv2d_fused: post_add channel range");
     a.y = d->y;

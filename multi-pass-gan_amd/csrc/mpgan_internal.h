@@ -42,6 +42,15 @@ __device__ __forceinline__ float apply_act(float v, int act, float leak) {
     return v;
 }
 
+// power-of-two scale that brings a tensor with absolute maximum `amax` into [2^8, 2^9): fp16 hi/lo splits of
+// gradients (1e-4 .. 1e-8 in magnitude) would otherwise land in the fp16 subnormal range
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(amax, &e);
+    return ldexpf(1.f, 9 - e);
+}
+
 // channel-chunk plan of one conv segment; shared by the packer and the kernel launch
 struct SegPlan {
     int kc;       // input channels per LDS chunk (multiple of 8)

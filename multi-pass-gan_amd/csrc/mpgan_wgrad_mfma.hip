@@ -27,13 +27,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BLK = 256;
 
-__device__ __forceinline__ float pow2_scale(float amax) {
-    // amax = m * 2^e, m in [0.5,1)  ->  scaled maximum in [2^8, 2^9)
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
-    int e;
-    frexpf(amax, &e);
-    return ldexpf(1.f, 9 - e);
-}
+using mpg::pow2_scale;
 
 __global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned int* __restrict__ out) {
     __shared__ float red[BLK];
@@ -301,6 +295,18 @@ inline size_t p16_elems(int n, int h, int w, int c) { return (size_t)n * h * c *
 
 }  // namespace
 
+extern "C" int mpg_absmax(mpg_stream_t stream, const float* x, size_t n, float* out) {
+    MPG_REQUIRE(x && out, "mpg_absmax: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = mpg::zero_async(out, sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_absmax: zero");
+    if (n == 0) return MPG_OK;
+    size_t b = (n + BLK * 16 - 1) / (BLK * 16);
+    if (b > 4096) b = 4096;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)b), dim3(BLK), 0, s, x, n, (unsigned int*)out);
+    MPG_LAUNCH_CHECK("absmax_kernel");
+}
+
 extern "C" size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout) {
     if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return 0;
     return 256 + (p16_elems(n, h, w, cin) + p16_elems(n, h, w, cout)) * sizeof(_Float16);
@@ -308,7 +314,7 @@ extern "C" size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, i
 
 extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
                                      const float* dy, int cout, int kh, int kw, float wscale, int prec,
-                                     void* workspace, size_t workspace_bytes, float* dw) {
+                                     void* workspace, size_t workspace_bytes, const float* dy_amax, float* dw) {
     MPG_REQUIRE(x && dy && dw && workspace, "mpg_conv2d_wgrad_mfma: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_wgrad_mfma: bad shape");
     MPG_REQUIRE(kh >= 1 && kh <= 7 && (kw == 1 || kw == 3 || kw == 4 || kw == 5),
@@ -328,7 +334,11 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
     auto am_grid = [](size_t n) { const size_t b = (n + BLK * 16 - 1) / (BLK * 16); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
     hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
-    hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nd)), dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
+    if (dy_amax != nullptr)      // the caller already reduced max |dy| (it scales the data gradient with it too)
+        e = hipMemcpyAsync(amax + 1, dy_amax, sizeof(float), hipMemcpyDeviceToDevice, s);
+    else
+        hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nd)), dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: copy of dy_amax");
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cin + 63) / 64), dim3(256), 0, s, x, h, w, cin, wp,
                        amax, xp);
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cout + 63) / 64), dim3(256), 0, s, dy, h, w, cout, wp,

@@ -32,8 +32,20 @@ class Cfg8x(object):
         self.bn_decay = bn_decay
         if upsampling_mode not in (1, 2, 3):
             raise NotImplementedError("upsampling_mode %d (only 1, 2, 3 are used by the example runs)" % upsampling_mode)
-        self.n_input = (tileSizeLow ** 2 if upsampling_mode == 2 else self.tileSizeHigh ** 2) * n_inputChannels
+        self.n_input = tileSizeLow ** 2 * n_inputChannels            # multipassGAN-8x.py:402-416 (modes 1, 2, 3)
         self.n_output = self.tileSizeHigh ** 2
+
+
+def later_network_input(x, y2, cfg):
+    """x_in of the second / third network (multipassGAN-8x.py:1041-1044): channel 1 of the two-channel `y`
+    (the previous pass's output; channel 0 is the target) next to the nearest-resized low-res input"""
+    c = cfg
+    y4 = tf.reshape(y2, shape=[-1, c.tileSizeHigh, c.tileSizeHigh, 2])
+    x_up = tf.resize_images(tf.reshape(x, shape=[-1, c.tileSizeLow, c.tileSizeLow, c.n_inputChannels]),
+                            [c.tileSizeHigh, c.tileSizeHigh], method=1)
+    x_in = tf.concat((tf.slice_channels(y4, 1, 1), x_up), axis=3)
+    y_in = tf.reshape(tf.slice_channels(y4, 0, 1), shape=[-1, c.tileSizeHigh * c.tileSizeHigh])
+    return x_in, y_in
 
 
 def growing_gen(_in, percentage, cfg, reuse=False, use_batch_norm=False, train=None, currentUpres=3, output=False):

@@ -61,7 +61,16 @@ def f8_available(cout):
     return 1 <= cout <= 128
 
 
-def to_g8(x, c_off=0, cin=None, flavour=G8_F16):
+def absmax(x):
+    """device scalar max |x| (mpg_absmax)"""
+    lib = _lib.load()
+    x = _dev(x.contiguous(), "x")
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_absmax(_stream(), _ptr(x), x.numel(), _ptr(out)), "mpg_absmax")
+    return out
+
+
+def to_g8(x, c_off=0, cin=None, flavour=G8_F16, amax=None):
     """fp32 NHWC x[..., c_off:c_off+cin] -> G8 (mpg_f32_to_g8)"""
     lib = _lib.load()
     x = _dev(x, "x")
@@ -71,7 +80,8 @@ def to_g8(x, c_off=0, cin=None, flavour=G8_F16):
     cin = c - c_off if cin is None else cin
     g = G8.empty(n, h, w, cin, x.device, flavour)
     if x.numel():
-        _lib.check(lib.mpg_f32_to_g8(_stream(), _ptr(x), n, h, w, c, c_off, cin, flavour, _ptr(g.buf)), "mpg_f32_to_g8")
+        _lib.check(lib.mpg_f32_to_g8_scaled(_stream(), _ptr(x), n, h, w, c, c_off, cin, flavour, _ptr(amax), _ptr(g.buf)),
+                   "mpg_f32_to_g8")
     return g
 
 
@@ -138,7 +148,8 @@ class Segment(object):
 
 
 def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=False, pn_eps=1e-8,
-                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, want_g8c=False, reserved=0):
+                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, want_g8c=False, reserved=0,
+                 in_amax=None):
     """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h.
     Returns the requested outputs in the order (fp32 NHWC, G8, G8 in the F16F8 flavour): a single
     object when one is requested, else a tuple."""
@@ -202,6 +213,8 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
     if not outs:
         raise _lib.MpgError("conv2d_fused: no output requested")
     d.prec, d.reserved = p0.prec, reserved
+    if in_amax is not None:     # the inputs were converted with to_g8(..., amax=in_amax): undo the power-of-two scale
+        d.in_amax = _dev(in_amax, "in_amax").data_ptr()
     _lib.check(lib.mpg_conv2d_fused(_stream(), ctypes.byref(d)), "mpg_conv2d_fused")
     return outs[0] if len(outs) == 1 else tuple(outs)
 

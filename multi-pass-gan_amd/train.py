@@ -25,10 +25,17 @@ def _mfma_ok(kh, kw, width, stride):
     return stride == (1, 1) and kh <= 7 and kw <= 7 and width <= 512
 
 
-def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0):
-    """conv2d_SAME(x, w * wscale) [+ bias, act] on the MFMA kernel, output channels in chunks of 128"""
+def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None):
+    """conv2d_SAME(x, w * wscale) [+ bias, act] on the MFMA kernel, output channels in chunks of 128.
+    rescale: x is a gradient (1e-4 .. 1e-8 in magnitude, below the fp16 normal range): it is split into
+    fp16 hi/lo after a power-of-two scaling by its absolute maximum, and the sum is scaled back in the epilogue"""
     cout = w.shape[3]
     outs = []
+    if not rescale:
+        amax = None
+    elif isinstance(x, torch.Tensor):
+        amax = ops.absmax(x) if amax is None else amax
+        x = ops.to_g8(x.contiguous(), 0, x.shape[3], ops.flavour_for(prec), amax=amax)
     for c0 in range(0, cout, 128):
         c1 = min(cout, c0 + 128)
         wc = w if (c0 == 0 and c1 == cout) else w[..., c0:c1].contiguous()
@@ -37,7 +44,7 @@ def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0):
         seg = ops.Segment(x, pk, pad_hi=pad_hi)
         if len(outs) == 0 and c1 < cout and isinstance(x, torch.Tensor):
             x = seg.x                       # reuse the G8 conversion for the other chunks
-        outs.append(ops.conv2d_fused([seg], (seg.x.h, seg.x.w), bias=bc, act=act, leak=leak))
+        outs.append(ops.conv2d_fused([seg], (seg.x.h, seg.x.w), bias=bc, act=act, leak=leak, in_amax=amax))
     return outs[0] if len(outs) == 1 else torch.cat(outs, dim=3)
 
 
@@ -88,16 +95,17 @@ class ConvLayerFn(torch.autograd.Function):
             d, dgamma, dbeta = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"])
         db = train_ops.channel_sum(d) if ctx.has_bias else None
         dw = None
+        d_amax = ops.absmax(d) if (stride == (1, 1) and not cfg.get("fc")) else None     # shared by both gradients
         if ctx.needs_input_grad[1]:
             if train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and cfg.get("wgrad_mfma", True):
-                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"])
+                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax)
             else:
                 dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale)
         dx = None
         if ctx.needs_input_grad[0]:
             if _mfma_ok(kh, kw, cin, stride) and not cfg.get("fc"):
                 wt = w.detach().flip(0, 1).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin], taps mirrored
-                dx = _mfma_conv(d, wt, wscale, cfg["prec"], pad_hi=1)
+                dx = _mfma_conv(d, wt, wscale, cfg["prec"], pad_hi=1, rescale=True, amax=d_amax)
             else:
                 dx = train_ops.conv2d_dgrad(d, w.detach(), (x.shape[1], x.shape[2]), stride, wscale)
         return dx, dw, db, dgamma, dbeta, None
@@ -126,7 +134,7 @@ def _conv_dgrad(dy, w, cfg, hw):
     kh, kw, cin, cout = w.shape
     if _mfma_ok(kh, kw, cin, cfg["stride"]) and not cfg.get("fc"):
         return _mfma_conv(dy.contiguous(), w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), cfg["wscale"], cfg["prec"],
-                          pad_hi=1)
+                          pad_hi=1, rescale=True)
     return train_ops.conv2d_dgrad(dy, w, hw, cfg["stride"], cfg["wscale"])
 
 
@@ -841,9 +849,17 @@ class Trainer8x(object):
         self.percentage = G.scalar_placeholder("percentage")
         self.x = G.placeholder([None, cfg.n_input], name="x")
         self.x_disc = G.placeholder([None, cfg.n_input], name="x_disc")
-        self.y_in = G.placeholder([None, cfg.n_output], name="y_in")
         self.y_gp = G.placeholder([None, cfg.n_output], name="y_gp")
-        self.gen_y = nets8x.growing_gen(self.x, self.percentage, cfg, train=True, currentUpres=self.currentUpres)
+        if cfg.upsampling_mode == 2:
+            self.y2 = None
+            self.y_in = G.placeholder([None, cfg.n_output], name="y_in")
+            x_in = self.x
+        else:       # later networks: `y` carries (target, previous pass) as two channels (:1041-1060)
+            if use_tempo:
+                raise NotImplementedError("temporal branch of the second / third network")
+            self.y2 = G.placeholder([None, cfg.n_output * 2], name="y")
+            x_in, self.y_in = nets8x.later_network_input(self.x, self.y2, cfg)
+        self.gen_y = nets8x.growing_gen(x_in, self.percentage, cfg, train=True, currentUpres=self.currentUpres)
         dk = dict(cfg=cfg, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
         self.disc, self.f_y = nets8x.growing_disc(self.y_in, self.x_disc, self.percentage, reuse=False, **dk)
         self.gen, self.f_g = nets8x.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
@@ -890,8 +906,13 @@ class Trainer8x(object):
         """-> dict of loss tensors (multipassGAN-8x.py:1082-1142); batch_ys at full tileSizeHigh resolution"""
         dev = self.sess.device
         xs = torch.as_tensor(batch_xs, dtype=torch.float32, device=dev)
-        ys = self._to_full_res(torch.as_tensor(batch_ys, dtype=torch.float32, device=dev))
-        feeds = {self.x: xs, self.x_disc: xs, self.y_in: ys, self.percentage: percentage}
+        ys = torch.as_tensor(batch_ys, dtype=torch.float32, device=dev)
+        if self.y2 is None:
+            ys = self._to_full_res(ys)
+            feeds = {self.x: xs, self.x_disc: xs, self.y_in: ys, self.percentage: percentage}
+        else:
+            feeds = {self.x: xs, self.x_disc: xs, self.y2: ys, self.percentage: percentage}
+            ys = ys.reshape(-1, self.cfg.n_output, 2)[:, :, 0].contiguous()        # the target channel
         out = self.sess.run([self.gen_y, self.disc, self.gen] + list(self.f_y) + list(self.f_g), feeds)
         nf = len(self.f_y)
         gen_y, disc, gen = out[0], out[1], out[2]

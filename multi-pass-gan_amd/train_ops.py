@@ -29,7 +29,7 @@ def wgrad_mfma_ok(kh, kw, stride):
     return tuple(stride) == (1, 1) and 1 <= kh <= 7 and kw in (1, 3, 4, 5)
 
 
-def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3):
+def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, dy_amax=None):
     """stride-1 weight gradient on the matrix cores (mpg_conv2d_wgrad_mfma)"""
     lib = _lib.load()
     x, dy = _cont(x, "x"), _cont(dy, "dy")
@@ -41,7 +41,7 @@ def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=x.device)
     _lib.check(lib.mpg_conv2d_wgrad_mfma(_stream(), _ptr(x), n, h, w, cin, _ptr(dy), cout, kh, kw, float(wscale), prec,
-                                         _ptr(ws), nbytes, _ptr(dw)), "mpg_conv2d_wgrad_mfma")
+                                         _ptr(ws), nbytes, _ptr(dy_amax), _ptr(dw)), "mpg_conv2d_wgrad_mfma")
     return dw
 
 

@@ -162,6 +162,61 @@ def tempo_losses_8x(p, batch_xts, batch_yts, batch_y_pos, tile_low, channels, pe
     return L
 
 
+def later_nets_losses_8x(p, batch_xs, batch_ys2, tile_low, channels, percentage=3.0, lerp_factor=None, filter_pn=True,
+                         wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, lambda_l1=1.0):
+    """second / third network (upsampling_mode 1 / 3, use_res_net, not firstNNArch; multipassGAN-8x.py
+    :1041-1060): y holds (target, previous pass); no resolution change inside generator or critic"""
+    th = tile_low * 8
+    xs = np.asarray(batch_xs, np.float32).reshape(-1, tile_low, tile_low, channels)
+    y2 = torch.tensor(np.asarray(batch_ys2), dtype=DT).reshape(-1, th, th, 2)
+    target = y2[..., 0:1].permute(0, 3, 1, 2)
+    prev = y2[..., 1:2].permute(0, 3, 1, 2)
+    x_up = torch.tensor(O.resize_nearest_tf1(xs, th, th), dtype=DT).permute(0, 3, 1, 2)
+    x_in = torch.cat([prev, x_up], dim=1)
+    g = "generator/"
+    x_g = res_block(p, g, x_in, "1")
+    x_g = res_block(p, g, x_g, "2")
+    old = conv(p, g + "g_cdensOut1", x_g, None, gain=1)
+    for j in range(1, 4):
+        up = 2 ** j
+        sc = g + "genBlock%d/" % up
+        x_g = res_block(p, sc, x_g, "first")
+        x_g = res_block(p, sc, x_g, "second")
+        dens = conv(p, sc + "g_cdensOut%d" % up, x_g, None, gain=1) + x_in[:, 0:1]
+        old = lerp(old, dens, percentage - (j - 1))
+    gen_y = old
+
+    def critic(high):
+        d = "spatial-disc/"
+        low = torch.tensor(O.resize_nearest_tf1(xs[..., :1], th, th), dtype=DT).permute(0, 3, 1, 2)
+        inp = torch.cat([low, high], dim=1)
+        x = conv(p, d + "d_cfromDensity8", inp)
+        for j in range(3, 0, -1):
+            x1 = conv(p, d + "dBlock%d/d_cA%d" % (2 ** j, 2 ** j), x, "lrelu")
+            x2 = conv(p, d + "dBlock%d/d_cB%d" % (2 ** j, 2 ** j), x1, "lrelu")
+            oldd = conv(p, d + "d_cfromDensity%d" % (2 ** (j - 1)), inp)
+            x = lerp(oldd, x2, percentage - (j - 1))
+        x1 = conv(p, d + "d_cA1", x, "lrelu")
+        x2 = conv(p, d + "d_cB1", x1)
+        flat = x2.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
+        w = p[d + "d_l61/weight"]
+        return flat @ (w * _ws(w, 1.0)) + p[d + "d_l61/bias"]
+
+    disc, gen = critic(target), critic(gen_y)
+    L = {"gen_y": gen_y}
+    disc_loss = (-disc).mean() + gen.mean()
+    if lerp_factor is not None:
+        lf = torch.tensor(np.asarray(lerp_factor), dtype=DT).reshape(-1, 1, 1, 1)
+        y_gp = (lf * target + (1 - lf) * gen_y.detach()).requires_grad_(True)
+        (gr,) = torch.autograd.grad(critic(y_gp).mean(), y_gp, create_graph=True)
+        norm = torch.sqrt(((gr.reshape(gr.shape[0], -1) + 1e-4) ** 2).sum(dim=1))
+        disc_loss = disc_loss + (disc ** 2).mean() * wgan_epsilon + (wgan_lambda * (norm - wgan_target) ** 2).mean()
+    L["disc_loss"] = disc_loss
+    L["l1_loss"] = (target - gen_y).abs().mean()
+    L["gen_loss_complete"] = (-gen).mean() + L["l1_loss"] * lambda_l1
+    return L
+
+
 def losses_8x(p, batch_xs, batch_ys, tile_low, channels, percentage=3.0, lerp_factor=None, lambda_l1=1.0, lambda2=0.0,
               wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True):
     """WGAN-GP losses of multipassGAN-8x.py:1082-1142 at the final growing stage's tile size"""

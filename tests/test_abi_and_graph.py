@@ -32,8 +32,9 @@ def test_struct_layout_matches_header(mpg):
     import ctypes
     from mpgan_amd import _lib
     assert ctypes.sizeof(_lib.ConvSeg) == 48
-    assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 48 + 72
+    assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 48 + 72 + 8
     assert _lib.ConvDesc.y_g8.offset == 264 and _lib.ConvDesc.y_g8c.offset == 272 and _lib.ConvDesc.reserved.offset == 284
+    assert _lib.ConvDesc.in_amax.offset == 288
 
 
 def test_compute_refuses_without_gpu(mpg):
