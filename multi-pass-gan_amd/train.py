@@ -126,7 +126,7 @@ def _conv_fwd(x, w, b, cfg):
         return train_ops.fc_forward(x.reshape(x.shape[0], cin), w.reshape(cin, cout), cfg["wscale"], b).reshape(
             x.shape[0], 1, 1, cout)
     if _mfma_ok(kh, kw, cout, cfg["stride"]):
-        return _mfma_conv(x.contiguous(), w.contiguous(), cfg["wscale"], cfg["prec"], b)
+        return _mfma_conv(x.contiguous(), w.contiguous(), cfg["wscale"], cfg["prec"], b, rescale=bool(cfg.get("rescale_fwd")))
     return ops.conv2d_direct(x.contiguous(), w.contiguous(), cfg["stride"], cfg["wscale"], None, b)
 
 
@@ -172,7 +172,8 @@ class ConvDgradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dy, w = ctx.saved_tensors
-        ddy = ConvFn.apply(g, w, None, ctx.cfg) if ctx.needs_input_grad[0] else None
+        # g is a gradient of a gradient: as small as dy itself, so the forward conv over it is abs-max scaled too
+        ddy = ConvFn.apply(g, w, None, dict(ctx.cfg, rescale_fwd=True)) if ctx.needs_input_grad[0] else None
         dw = ConvWgradFn.apply(g, dy, ctx.cfg, w.shape[0], w.shape[1]) if ctx.needs_input_grad[1] else None
         return ddy, dw, None, None
 
