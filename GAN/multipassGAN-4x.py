@@ -9,8 +9,9 @@ reference (example_run_output.py:4-8):
   upsamplingMode 2, upsampledData 0 : zoom z, slices along z  -> density_low_2x2_%04d.uni
   upsamplingMode 1, upsampledData 1 : slices along x          -> density_low_1x1_%04d.uni
 
-Training mode (``out 0``) trains the first network (upsamplingMode 2, upsampledData 0) the way the
-reference loop does (:196-300 data, :728-902 graph, :1300-1360 iteration): FluidDataLoader slices ->
+Training mode (``out 0``) trains the first network (upsamplingMode 2, upsampledData 0) or the second one
+(upsamplingMode 1, upsampledData 1: slices of the zoomed volumes with the first network's output as density) the way
+the reference loop does (:196-300 data, :728-902 graph, :1300-1360 iteration): FluidDataLoader slices ->
 TileCreator tiles (augmentation, coherent triples) -> ``train.Trainer4x`` (spatial + temporal
 discriminator) -> ``basePath/test_%04d/model_%04d.ckpt.npz``.
 """
@@ -68,8 +69,10 @@ def train_main():
     """multipassGAN-4x.py with `out 0`, first network"""
     from mpgan_amd import tilecreator_t as tc
     from mpgan_amd.train import Trainer4x
-    if int(P["upsamplingMode"]) != 2 or int(P["upsampledData"]) or int(P["dataDim"]) != 2:
-        print("ERROR: training is implemented for the first network (upsamplingMode 2, upsampledData 0, dataDim 2)")
+    mode, upsampled = int(P["upsamplingMode"]), int(P["upsampledData"])
+    if int(P["dataDim"]) != 2 or (mode, upsampled) not in ((2, 0), (1, 1)):
+        print("ERROR: training is implemented for the first network (upsamplingMode 2, upsampledData 0) and the second "
+              "one (upsamplingMode 1, upsampledData 1), dataDim 2")
         exit(1)
     if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
         print("ERROR: vorticity / flag / k-eps inputs and premade tiles are not supported")
@@ -88,7 +91,24 @@ def train_main():
         mfl = mfl + ["velocity"]
     dirIDs = np.linspace(fromSim, toSim, (toSim - fromSim + 1), dtype='int16')
     data_fraction = float(P["data_fraction"])
-    if not useTempoD:
+    if mode == 1:
+        # second network (:234,241-248,253-262,291-299): slices along x of volumes zoomed to the high resolution,
+        # their density channel replaced by the first network's output (density_low_2x2_%04d.uni)
+        n_t = 3
+        mol = [o for o in range(3) for _ in mfl]
+        moh = [o for o in range(3) for _ in mfh]
+        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow * upRes, densityMinimum=0.005, channelLayout_high='d',
+                              simSizeLow=simSizeLow * upRes, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=1,
+                              premadeTiles=False)
+        common = dict(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
+                      conv_slices=True, conv_axis=2, select_random=0.1, density_threshold=0.002,
+                      axis_scaling_y=[1, 1, 1, 1], axis_scaling=[upRes, upRes, upRes, 1], filename="density_low_%04d.uni",
+                      oldNamingScheme=False, filename_index_max=frame_max, filename_index_min=frame_min, indices=dirIDs,
+                      data_fraction=data_fraction, multi_file_list_y=mfh * 3, multi_file_idxOff_y=moh)
+        fl2 = FDL.FluidDataLoader(filename_y="density_low_2x2_%04d.uni", multi_file_list=["density"] * 3,
+                                  multi_file_idxOff=[0, 1, 2], **common)
+        fl = FDL.FluidDataLoader(filename_y="density_high_%04d.uni", multi_file_list=mfl * 3, multi_file_idxOff=mol, **common)
+    elif not useTempoD:
         tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, simSizeLow=simSizeLow, dim=2, dim_t=1, channelLayout_low=channelLayout_low,
                               upres=upRes, premadeTiles=False, channelLayout_high='d')
         fl = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
@@ -115,7 +135,15 @@ def train_main():
         tiCr.initDataAugmentation(rot=int(P["rot"]), minScale=float(P["minScale"]), maxScale=float(P["maxScale"]),
                                   flip=int(P["flip"]))
     x, y, _ = fl.get()
-    x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_ch * n_t)          # :288-290
+    if mode == 1:
+        _, x_2, _ = fl2.get()
+        x = x.reshape(-1, 1, simSizeHigh, simSizeHigh, n_ch * n_t)    # :292-297
+        x_2 = x_2.reshape(-1, 1, simSizeHigh, simSizeHigh, n_t)
+        for i in range(n_ch * n_t):
+            if i % n_ch == 0:
+                x[:, :, :, :, i:i + 1] = x_2[:, :, :, :, i // n_ch:i // n_ch + 1]
+    else:
+        x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_ch * n_t)      # :288-290
     y = y.reshape(-1, 1, simSizeHigh, simSizeHigh, n_t)
     tiCr.addData(x, y)
     np.random.seed(randSeed)
@@ -124,7 +152,7 @@ def train_main():
     ph.writeParams(test_path + "params.json")
     batch = int(P["batchSize"])
     trainer = Trainer4x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_ch, batch_norm=batch_norm,
-                        upsampling_mode=2, device=device, learning_rate=float(P["learningRate"]),
+                        upsampling_mode=mode, device=device, learning_rate=float(P["learningRate"]),
                         beta1=float(P["adam_beta1"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
                         lambda2_l=tuple(float(P["lambda2_l%d" % i]) for i in (1, 2, 3, 4)),
                         weight_dld=float(P["weight_dld"]), bn_decay=float(P["bnDecay"]), seed=randSeed,
@@ -137,7 +165,8 @@ def train_main():
                     t_.copy_(torch.as_tensor(params[n_], device=t_.device))
         print("Model restored.")
     aug = int(P["dataAugmentation"]) > 0
-    n_in, n_out = tileSizeLow * tileSizeLow * n_ch, (tileSizeLow * upRes) ** 2
+    n_out = (tileSizeLow * upRes) ** 2
+    n_in = (tileSizeLow * tileSizeLow if mode == 2 else n_out) * n_ch
 
     def getinput():
         bx, by = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)

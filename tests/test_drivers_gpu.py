@@ -188,3 +188,31 @@ def test_8x_training_driver(tmp_path):
              "load_model_test_3", -1, "load_model_no_3", -1, "use_res_net3", 0, "add_adj_idcs3", 0, "startFms3", 192,
              "maxFms3", 96, "filterSize3", 5]
     _run("multipassGAN-out.py", oargs, str(tmp_path))
+
+
+def test_4x_training_driver_second_network(tmp_path):
+    """`out 0 upsamplingMode 1 upsampledData 1`: the second 4x network trains on slices along x of the zoomed
+    volumes whose density channel is the first network's output (density_low_2x2_%04d.uni)"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import checkpoint, uniio
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, up, frames = 4, 4, 9
+    d = tmp_path / "data" / "sim_1005"
+    d.mkdir(parents=True)
+    (tmp_path / "models").mkdir()
+    hs = sim * up
+    for f in range(frames):
+        v = synthetic_volume(sim, 4, f)
+        uniio.writeUni(str(d / ("density_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim), v[..., 0:1] + 0.05)
+        uniio.writeUni(str(d / ("velocity_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim, vec3=True), v[..., 1:4])
+        for seed, nm in ((100, "density_high_%04d.uni"), (200, "density_low_2x2_%04d.uni")):
+            uniio.writeUni(str(d / (nm % f)), uniio.make_header(hs, hs, hs), synthetic_volume(hs, 1, seed + f) + 0.05)
+    args = ["upRes", up, "out", 0, "tileSize", 2, "simSize", sim, "fromSim", 1005, "toSim", 1005, "dataDim", 2,
+            "useVelocities", 1, "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/",
+            "frame_min", 0, "frame_max", 6, "genModel", "gen_resnet", "discModel", "disc_binclass", "randSeed", 43,
+            "batchSize", 3, "trainingEpochs", 2, "outputInterval", 1, "saveInterval", 10, "lambda", 5.0, "lambda_t", 1.0,
+            "data_fraction", 1.0, "dataAugmentation", 0, "upsamplingMode", 1, "upsampledData", 1, "batchNorm", 1]
+    out = _run("multipassGAN-4x.py", args, str(tmp_path))
+    assert "TRAINING FINISHED" in out and "Epoch 00002/2" in out
+    p = checkpoint.load(str(tmp_path / "models" / "test_0000" / "model_0000.ckpt"))
+    assert p["generator/g_cA0/weight"].shape == (5, 5, 4, 8) and all(np.isfinite(v).all() for v in p.values())
