@@ -137,6 +137,9 @@ def main():
                     help="2 = MPG_PREC_F16F8 (default), 3 = MPG_PREC_F16X3, 1 = MPG_PREC_F16X1 (outside the 1e-3 tolerance)")
     ap.add_argument("--slice-batch", type=int, default=8, help="slices per generator launch (reference: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="sharded", choices=("sharded", "replicas"),
+                    help="N > 1: shard every volume's slices over the ranks with an all-gather between the passes "
+                         "(default, north_star), or give every rank its own whole volumes and exchange nothing")
     args = ap.parse_args()
 
     import mpgan_amd
@@ -158,13 +161,15 @@ def main():
     cfg2 = dict(tile_low=SIM, up_res=UP, channels=1, upsampling_mode=1, batch_norm=True)
     g1 = MP.Generator("gen_resnet", cfg1, None, args.prec, device=device, seed=777)
     g2 = MP.Generator("gen_resnet", cfg2, None, args.prec, device=device, seed=778)
-    lows_np = [synthetic_volume(SIM, 1, i) for i in range(n_vol)]
+    replicas = args.mode == "replicas" and world > 1
+    mine = range(rank * args.volumes_per_gpu, (rank + 1) * args.volumes_per_gpu) if replicas else range(n_vol)
+    lows_np = [synthetic_volume(SIM, 1, i) for i in mine]
     lows = [torch.as_tensor(v).to(device) for v in lows_np]       # resident in HBM before the timed region
 
     def step():
         # the volumes are independent: their passes are pipelined by one volume so that the all-gather of
         # one volume's slabs overlaps the convolutions of its neighbours (N > 1); same arithmetic either way
-        return MP.two_pass_4x_batch(g1, g2, lows, UP, batch=args.slice_batch, comm=comm)
+        return MP.two_pass_4x_batch(g1, g2, lows, UP, batch=args.slice_batch, comm=None if replicas else comm)
 
     for _ in range(args.warmup):
         step()
@@ -188,8 +193,8 @@ def main():
         r1 = MP.Generator("gen_resnet", cfg1, g1.params(), 3, device=device)
         r2 = MP.Generator("gen_resnet", cfg2, g2.params(), 3, device=device)
         ref, _ = MP.two_pass_4x(r1, r2, lows[0], UP, batch=args.slice_batch)
-        if comm is None:
-            parity = float(((outs[0].double() - ref.double()).norm() / ref.double().norm()).item())
+        # (sharded runs all-gather the slabs, so volume 0 is whole on rank 0 in every mode)
+        parity = float(((outs[0].double() - ref.double()).norm() / ref.double().norm()).item())
         del r1, r2, ref
 
     if rank != 0:
@@ -214,7 +219,9 @@ def main():
             "volumes_per_step": n_vol,
             "slices_per_volume": SLICES_PER_VOLUME,
             "slice_batch": args.slice_batch,
-            "parallelism": "slice-axis sharding x%d + all-gather between passes, exchanges overlapped with the next volume" % world if world > 1 else "single GPU",
+            "parallelism": ("whole volumes per rank x%d, no exchange" % world if replicas else
+                            "slice-axis sharding x%d + all-gather between passes, exchanges overlapped with the next volume" % world)
+                           if world > 1 else "single GPU",
             "precision": {3: "MPG_PREC_F16X3 (fp16 hi/lo split, three fp16 MFMA products, fp32 accumulate)",
                           2: "MPG_PREC_F16F8 (fp16 product + two fp8 MX correction products, fp32 accumulate)",
                           1: "MPG_PREC_F16X1 (outside the 1e-3 tolerance)"}[args.prec],
