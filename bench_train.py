@@ -61,10 +61,17 @@ def wgrad_roofline(device, tile_high, batch, iters=10, k=5, c=128):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * k * k * c * c * tile_high * tile_high * batch
     ach = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per call from the committed PMC passes (profiles/r01/roofline_pmc_wgrad.json), which were taken
+    # on exactly one shape; other shapes report null
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "roofline_pmc_wgrad.json")
+    if (k, c, batch, tile_high) == (5, 128, 16, 256) and os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f)["hbm_bytes_per_call"]
     return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_mfma %dx%d %d->%d (absmax + P16 rewrite + wgrad_mfma_kernel), "
                                        "%d tiles of %d^2" % (k, k, c, c, batch, tile_high),
             "achieved": round(ach, 2), "peak": DENSE_F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / DENSE_F16_MFMA_PEAK_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+            "frac": round(ach / DENSE_F16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_products_per_mac": "3 fp16"}
 
 

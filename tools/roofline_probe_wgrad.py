@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Launches the dominant kernel of the training benches (matrix-core weight gradient of a 5x5 128->128 conv on 16
+tiles of 256^2: abs-max + P16 rewrite + wgrad_mfma_kernel<5,2,3> x2) a few times; run under
+`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) to get the HBM traffic per kernel."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import mpgan_amd  # noqa: F401
+from mpgan_amd import train_ops
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(1)
+x = torch.randn((16, 256, 256, 128), device=dev, generator=g).relu_()
+dy = torch.randn((16, 256, 256, 128), device=dev, generator=g) * 1e-4
+for _ in range(iters):
+    train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3)
+torch.cuda.synchronize()
+print("done")
