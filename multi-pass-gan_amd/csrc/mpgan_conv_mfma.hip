@@ -43,6 +43,7 @@ struct SegArgs {
     int np;               // pixels per image plane, padded to a multiple of 64
     int ni_img;           // image DMA instructions per thread per chunk
     int sw_hi, sw_lo;     // F16F8: E8M0 scale words (replicated bytes) of the fp8 weight planes
+    int direct;           // F16F8, 1x1 over >= 2 groups: B fragments straight from memory, K runs over groups
 };
 
 struct ConvArgs {
@@ -459,6 +460,89 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 
     for (int s = 0; s < ((a.dbg & 1) ? 0 : a.nseg); ++s) {
         const auto& sg = ap->seg[s];
+        if (NT <= 2 && sg.direct) {
+            // 1x1 segment over cg_seg >= 2 channel groups: no halo, so no LDS image.  The G8 rows are already
+            // fragment-shaped (16 B per pixel and group): lane (pixel r, half hh) loads its B operands from
+            // memory, a weight stage is one macro-step of 8 GROUPS (K = 64) instead of 8 taps.  Rows / columns
+            // past the image edge re-read the last valid pixel; their outputs are never stored.
+            const unsigned plane_bytes = (unsigned)(sg.hs * sg.ws) * 16u;   // host: 16 planes < 2^31 bytes
+            const unsigned gstride = 2u * plane_bytes;
+            const char* xb = sg.x + ((size_t)n * sg.cg_total + sg.g_off) * gstride;   // uniform
+            unsigned pixo[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                int yy = y0 + PT * wave + pt, xx = x0 + r;
+                yy = (yy < a.h ? yy : a.h - 1) >> sg.up;
+                xx = (xx < a.w ? xx : a.w - 1) >> sg.up;
+                pixo[pt] = (unsigned)(yy * sg.ws + xx) * 16u;
+            }
+            const int glast = sg.cg_seg - 1;
+            auto dma_stage_d = [&](int stage) {
+                const int sidx = stage < sg.sc ? stage : sg.sc - 1;
+                const char* src = sg.w + (size_t)sidx * WSTAGE + tid * 16;
+                char* dst = w_lds + (stage % R) * WSTAGE + wave_u * 1024;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) dma16(src + i * (THREADS * 16), dst + i * (THREADS * 16));
+            };
+#pragma unroll
+            for (int d = 0; d < D; ++d) dma_stage_d(d);
+            for (int st = 0; st < sg.sc; ++st) {
+                wait_dma_and_barrier<(D - 1) * NI>();
+                dma_stage_d(st + D);
+                const char* wb = w_lds + (st % R) * WSTAGE;
+                const char* xs = xb + (size_t)st * 8 * gstride;   // uniform: first group of this macro-step
+                const int grem = glast - st * 8;
+                half8 b_hi[4][PT];
+                v8i b8_hi[PT], b8_lo[PT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int g = 2 * j + hh;
+                    g = g < grem ? g : grem;                 // groups past the segment: zero weights
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) b_hi[j][pt] = *reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride));
+                }
+                {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int g = 4 * hh + i;
+                        g = g < grem ? g : grem;
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) {
+                            const int4 v = *reinterpret_cast<const int4*>(xs + (pixo[pt] + g * gstride + plane_bytes));
+                            b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
+                            b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                            for (int pt = 0; pt < PT; ++pt)
+                                acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[j][pt], acc[pt][nt], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const v8i w8_hi = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
+                    const v8i w8_lo = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
+                                                                                   sg.sw_hi, 0, sa_lo);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_lo, b8_hi[pt], acc[pt][nt], 0, 0, 0,
+                                                                                   sg.sw_lo, 0, sa_hi);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            continue;
+        }
         const int T = sg.kh * sg.kw;
         const int plane_b = sg.np * 16;
         const int ppg = sg.np >> 6;
@@ -570,7 +654,9 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 //   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][64 lanes][32 x fp8 hi]  |  [NT][64 lanes][32 x fp8 lo]
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                        int cin, int cout, float wscale, const float* __restrict__ cscale,
-                                       int NT, int nchunks, int sc, float s_hi, float s_lo, char* __restrict__ out) {
+                                       int NT, int nchunks, int sc, float s_hi, float s_lo, int fold,
+                                       char* __restrict__ out) {
+    // fold (direct 1x1 segments): one chunk, the "taps" of a macro-step are 8 consecutive channel groups
     const int T = kh * kw;
     const long per_stage = (long)NT * 64 * 64;      // one thread per (nt, lane, byte-slot b in 0..63)
     const long total = (long)nchunks * sc * per_stage;
@@ -587,7 +673,8 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int 
     const size_t stage_b = (size_t)8 * NT * 1024;
     char* base = out + ((size_t)c * sc + st) * stage_b;
     auto weight = [&](int tap, int j) -> float {
-        const int chn = c * 8 + j;
+        const int chn = fold ? tap * 8 + j : c * 8 + j;
+        if (fold) tap = 0;
         if (tap >= T || chn >= cin || co >= cout) return 0.f;
         float v = w[((size_t)tap * cin_total + c_off + chn) * cout + co] * wscale;
         if (cscale != nullptr) v *= cscale[co];
@@ -876,7 +963,7 @@ Shape pipe_shape(int nt, int prec) {
 }
 
 struct SegShape {
-    int cgc, nchunks, sc, np, ni_img, img_bytes;
+    int cgc, nchunks, sc, np, ni_img, img_bytes, direct;
 };
 
 // groups per chunk: two when that removes the half-empty k-step of an odd tap count and the
@@ -889,6 +976,7 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
     const int np = (px + 63) & ~63;
     const int ring = ps.r * ps.ks * nt * 1024 * npl;
     SegShape s;
+    s.direct = 0;
     s.np = np;
     s.cgc = 1;
     if (cg >= 2 && ((kh * kw) & 1)) {
@@ -910,6 +998,13 @@ int f8_waves(int nt) { return nt == 1 ? 4 : 8; }
 
 SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
     SegShape s;
+    s.direct = 0;
+    if (kh == 1 && kw == 1 && cin > 8 && nt <= 2) {   // conv_mfma_f8_kernel's direct path: K over channel groups
+        s.direct = 1; s.cgc = 1; s.np = 0; s.ni_img = 0; s.img_bytes = 0;
+        s.nchunks = 1;
+        s.sc = ((cin + 7) / 8 + 7) / 8;
+        return s;
+    }
     const int waves = f8_waves(nt);
     const int px = (16 + kh - 1) * (TW + kw - 1);
     s.np = (px + 63) & ~63;
@@ -1041,7 +1136,7 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
         const long total = (long)ss.nchunks * ss.sc * nt * 64 * 64;
         hipLaunchKernelGGL(pack_weights_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                            w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ss.nchunks, ss.sc,
-                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), (char*)out);
+                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), ss.direct, (char*)out);
         if (small_layer(cin, cout))
             hipLaunchKernelGGL(pack_small_kernel, dim3((kh * kw * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio,
                                kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
@@ -1142,6 +1237,9 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         o.pt = g.pad_hi ? g.kh / 2 : (g.kh - 1) / 2; o.pl = g.pad_hi ? g.kw / 2 : (g.kw - 1) / 2;
         o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2;
         o.np = ss.np; o.ni_img = ss.ni_img;
+        o.direct = ss.direct;
+        MPG_REQUIRE(!ss.direct || (size_t)(d->h >> g.up_log2) * (d->w >> g.up_log2) * 16 * 16 < ((size_t)1 << 31),
+                    "mpg_conv2d_fused: segment %d: %dx%d too large for the 1x1 path (32-bit group offsets)", s, d->h, d->w);
         o.sw_hi = o.sw_lo = 0;
         if (f8) {
             MPG_REQUIRE(g.w_exp >= -100 && g.w_exp <= 100, "mpg_conv2d_fused: segment %d w_exp %d", s, g.w_exp);

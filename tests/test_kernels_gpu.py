@@ -156,6 +156,41 @@ def test_f16f8_chain_and_flavour_check(gpu_ops, mpg):
         gpu_ops.conv2d_fused([gpu_ops.Segment(gpu_ops.to_g8(_t(x)), p1)], (16, 32))
 
 
+def test_f16f8_direct_1x1_segments(gpu_ops):
+    """1x1 segments over >= 2 channel groups on the F16F8 kernels with <= 64 outputs read their B fragments
+    straight from memory, K running over channel groups (the 128 -> 8 shortcut of resBlock 2,
+    multipassGAN-4x.py:517-523): ragged tiles, partial macro-steps, a channel window, a fused upsample, and
+    small integers for the fragment layout."""
+    rng = _rng(4242)
+    # resBlock-2 shape on ragged tiles
+    n, h, w = 2, 19, 40
+    a = np.abs(rng.standard_normal((n, h, w, 32))).astype(np.float32)
+    x = np.abs(rng.standard_normal((n, h, w, 128))).astype(np.float32)
+    wb = rng.standard_normal((5, 5, 32, 8)).astype(np.float32)
+    wsk = rng.standard_normal((1, 1, 128, 8)).astype(np.float32)
+    wsb, wss = float(O.wscale(wb.shape)), float(O.wscale(wsk.shape))
+    ref = O.relu(O.conv2d_same(a, wb * np.float32(wsb)) + O.conv2d_same(x, wsk * np.float32(wss)))
+    ga = gpu_ops.to_g8(_t(a), flavour=gpu_ops.G8_F8C)
+    gx = gpu_ops.to_g8(_t(x), flavour=gpu_ops.G8_F8C)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(ga, gpu_ops.pack_conv_weights(_t(wb), wscale=wsb, prec=2)),
+                              gpu_ops.Segment(gx, gpu_ops.pack_conv_weights(_t(wsk), wscale=wss, prec=2))], (h, w), act="relu")
+    assert rel_l2(y.cpu().numpy(), ref) < 1.5e-4
+    # 9 groups (one full + one partial macro-step), 64 outputs, source at half resolution
+    xl = np.abs(rng.standard_normal((1, 16, 24, 72))).astype(np.float32)
+    w1 = rng.standard_normal((1, 1, 72, 64)).astype(np.float32) * 0.1
+    ref = O.conv2d_same(O.resize_nearest_tf1(xl, 32, 48), w1)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(gpu_ops.to_g8(_t(xl), flavour=gpu_ops.G8_F8C),
+                                              gpu_ops.pack_conv_weights(_t(w1), prec=2), up_log2=1)], (32, 48))
+    assert rel_l2(y.cpu().numpy(), ref) < 1.5e-4
+    # channel window [8, 108) of a 120-channel tensor; integers are exact in every operand format
+    xi = rng.integers(-3, 4, size=(1, 16, 32, 120)).astype(np.float32)
+    wi = rng.integers(-2, 3, size=(1, 1, 100, 24)).astype(np.float32)
+    ref = O.conv2d_same(xi[..., 8:108], wi)
+    y = gpu_ops.conv2d_fused([gpu_ops.Segment(gpu_ops.to_g8(_t(xi), flavour=gpu_ops.G8_F8C),
+                                              gpu_ops.pack_conv_weights(_t(wi), prec=2), c_off=8)], (16, 32))
+    assert np.array_equal(y.cpu().numpy(), ref)
+
+
 def test_conv2d_fused_exact_integers(gpu_ops):
     """Small-integer data is exact in fp16: the MFMA path must be bit-exact, which pins
     the fragment layouts (asymmetric weights catch a transposed operand map)."""
