@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """8x progressive-growing training driver: the ``name value`` command line of the reference's
-GAN/multipassGAN-8x.py (params :30-158) as example_run_training.py issues it for the FIRST network
-(upsamplingMode 2: low-res slices in, 8x slices out).
+GAN/multipassGAN-8x.py (params :30-158) as example_run_training.py issues it for the first network
+(upsamplingMode 2, upsampledData 0: low-res slices in, 8x slices out, three growing stages) and for the second /
+third network (upsamplingMode 1 / 3, upsampledData 1: slices along the next axis, the previous network's output
+volumes ``density_low_t%04d_2x2_%04d.uni`` / ``..._1x1_...`` as an extra high-res input channel, :231-238,:361-366).
 
 What is rebuilt (reference line numbers): the data path :196-345 (FluidDataLoader slices of three
 coherent frames with the add_adj_idcs neighbour channels, intermediate-resolution targets
@@ -11,8 +13,8 @@ stage completes), the iteration :1990-2060 (spatial critic, temporal critic on a
 through ``train.Trainer8x``, the polynomial learning-rate decay :995-1009 after 6 * stageIter iterations,
 checkpoints ``model_%04d.ckpt.npz`` and the moving-average weights ``model_ema_%04d.ckpt.npz`` :1804-1812.
 
-Not rebuilt: output mode (use multipassGAN-out.py), the second / third networks (upsamplingMode 1 / 3 with
-upsampledData), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
+Not rebuilt: output mode (use multipassGAN-out.py), upsamplingMode 0 (the linear-interpolation variant no example
+run uses), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
 scaling (lossScaling is accepted and ignored: the arithmetic is fp32-grade), PNG test images, TensorBoard.
 """
 import math
@@ -66,8 +68,11 @@ def fail(msg):
 
 if int(P["out"]) > 0:
     fail("output mode of the 8x networks is GAN/multipassGAN-out.py")
-if int(P["upsamplingMode"]) != 2 or int(P["upsampledData"]) or int(P["dataDim"]) != 2:
-    fail("training is implemented for the first network (upsamplingMode 2, upsampledData 0, dataDim 2)")
+upsampling_mode, upsampled_data = int(P["upsamplingMode"]), int(P["upsampledData"])
+if (upsampling_mode, upsampled_data) not in ((2, 0), (1, 1), (3, 1)) or int(P["dataDim"]) != 2:
+    fail("training is implemented for the first network (upsamplingMode 2, upsampledData 0) and the second / third "
+         "one (upsamplingMode 1 / 3, upsampledData 1), dataDim 2")
+later_net = upsampling_mode != 2
 if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
     fail("vorticity / flag / k-eps inputs and premade tiles are not supported")
 if int(P["batchNorm"]) or int(P["usePixelShuffle"]) or int(P["use_mb_stddev"]) or int(P["gDrop"]) or int(P["useVelInTDisc"]):
@@ -96,13 +101,19 @@ batch = int(P["batchSize"])
 aug = int(P["dataAugmentation"]) > 0
 device = "cuda:0"
 
-channelLayout_low, mfl, mfh = 'd', ["density"], ["density"]
+channelLayout_low, channelLayout_high, mfl, mfh = 'd', ('d,d' if later_net else 'd'), ["density"], ["density"]
 if useVelocities:
     channelLayout_low += ',vx,vy,vz'
     mfl = mfl + ["velocity"]
 if add_adj_idcs:
     channelLayout_low += ',d,d'
 n_inputChannels = len(channelLayout_low.split(','))
+if later_net and int(P["firstNNArch"]):
+    fail("firstNNArch belongs to the first network")
+# previous network's output volumes (:231-238) and the slicing axis of this pass (:301-307)
+outNNTestNo = int(P["outNNTestNo"])
+lowfilename_2 = {1: "density_low_t%04d_2x2" % outNNTestNo + "_%04d.uni", 3: "density_low_t%04d_1x1" % outNNTestNo + "_%04d.uni"}.get(upsampling_mode)
+transpose_axis = {2: 0, 1: 2, 3: 1}[upsampling_mode]
 dirIDs = np.linspace(fromSim, toSim, (toSim - fromSim + 1), dtype='int16')
 mol = [o for o in range(3) for _ in mfl]
 moh = [o for o in range(3) for _ in mfh]
@@ -111,30 +122,46 @@ stride = 3
 
 def load_stage(currentUpres, first):
     """TileCreator + data of one growing stage (:290-345 at start-up, :1920-1960 at a stage change)"""
-    tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.002 if first else 0.01, channelLayout_high='d',
+    tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.002 if first else 0.01, channelLayout_high=channelLayout_high,
                           simSizeLow=simSizeLow, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=currentUpres,
                           premadeTiles=False)
     high = "density_high_%04d.uni" if currentUpres == upRes else "density_low_%i" % currentUpres + "_%04d.uni"
     off = 0 if first else stride * (int(round(math.log(currentUpres, 2))) - 1)
-    fl = FDL.FluidDataLoader(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
-                             add_adj_idcs=add_adj_idcs, conv_slices=True, conv_axis=0,
-                             select_random=0.4 if first else 1.0, density_threshold=0.005 if first else 0.002,
-                             axis_scaling_y=[1, 1, 1, 1], axis_scaling=[currentUpres, 1, 1, 1],
-                             filename="density_low_%04d.uni", oldNamingScheme=False, filename_y=high,
-                             filename_index_max=frame_max + off, filename_index_min=frame_min + off, indices=dirIDs,
-                             data_fraction=max(data_fraction * 2 / currentUpres, min_data_fraction) if first else data_fraction,
-                             multi_file_list=mfl * 3, multi_file_idxOff=mol, multi_file_list_y=mfh * 3, multi_file_idxOff_y=moh)
+    common = dict(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
+                  add_adj_idcs=add_adj_idcs, conv_slices=True, conv_axis=transpose_axis,
+                  select_random=(0.2 if later_net else 0.4) if first else 1.0, density_threshold=0.005 if first else 0.002,
+                  axis_scaling_y=[1, 1, 1, 1], axis_scaling=[currentUpres, 1, 1, 1], filename="density_low_%04d.uni",
+                  oldNamingScheme=False, filename_index_max=frame_max + off, filename_index_min=frame_min + off,
+                  indices=dirIDs, multi_file_list_y=mfh * 3, multi_file_idxOff_y=moh)
+    first_fraction = max(data_fraction * 2 / currentUpres, min_data_fraction)
+    x_2 = None
+    if later_net:      # the same slices of the previous network's output, read as the `y` of a density-only loader (:324-333)
+        fl2 = FDL.FluidDataLoader(filename_y=lowfilename_2, data_fraction=first_fraction, multi_file_list=["density"] * 3,
+                                  multi_file_idxOff=[0, 1, 2], **common)
+    fl = FDL.FluidDataLoader(filename_y=high, data_fraction=first_fraction if first else data_fraction,
+                             multi_file_list=mfl * 3, multi_file_idxOff=mol, **common)
     if aug:
         tiCr.initDataAugmentation(rot=int(P["rot"]), minScale=float(P["minScale"]), maxScale=float(P["maxScale"]),
                                   flip=int(P["flip"]))
     x, y, _ = fl.get()
-    x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_inputChannels * 3)
-    y = y.reshape(-1, 1, simSizeLow * currentUpres, simSizeLow * currentUpres, 3)
+    if later_net:
+        _, x_2, _ = fl2.get()
+    simSizeHigh = simSizeLow * upRes
+    if not later_net:
+        x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_inputChannels * 3)
+        y = y.reshape(-1, 1, simSizeLow * currentUpres, simSizeLow * currentUpres, 3)
+    else:
+        # (:372-376) per frame the pair (target, previous pass): the reference's reshape / concatenate / reshape of
+        # the three-frame arrays is this interleave of their last axes
+        x = x.reshape(-1, 1, simSizeLow, simSizeLow, n_inputChannels * 3)
+        y = y.reshape(-1, 1, simSizeHigh, simSizeHigh, 3)
+        x_2 = x_2.reshape(-1, 1, simSizeHigh, simSizeHigh, 3)
+        y = np.stack((y, x_2), axis=-1).reshape(-1, 1, simSizeHigh, simSizeHigh, 6)
     tiCr.addData(x, y)
     return tiCr
 
 
-currentUpres = min(2 ** (startingIter // (stageIter * 2) + 1), 8)   # :215
+currentUpres = 8 if later_net else min(2 ** (startingIter // (stageIter * 2) + 1), 8)   # :213-217
 tiCr = load_stage(currentUpres, True)
 print("Random seed: {}".format(randSeed))
 np.random.seed(randSeed)
@@ -145,7 +172,7 @@ ph.writeParams(test_path + "params.json")
 from mpgan_amd.nets8x import Cfg8x  # noqa: E402
 from mpgan_amd.train import Trainer8x  # noqa: E402
 
-cfg = Cfg8x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_inputChannels, upsampling_mode=2,
+cfg = Cfg8x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_inputChannels, upsampling_mode=upsampling_mode,
             upsampleMode=int(P["upsampleMode"]), filterSize=int(P["filterSize"]), start_fms=int(P["startFms"]),
             max_fms=int(P["maxFms"]), first_nn_arch=int(P["firstNNArch"]) > 0, use_res_net=int(P["use_res_net"]) > 0,
             pixel_norm=int(P["pixelNorm"]) > 0, addBicubicUpsample=int(P["addBicubicUpsample"]) > 0,

@@ -831,7 +831,7 @@ class Trainer8x(object):
     :1305-1362): WGAN-GP (lambda 10, target 1, epsilon penalty 1e-3) or LSGAN or sigmoid-CE losses, L1 and
     layer losses for the generator, Adam(beta1, beta2) per network, and the 0.999 moving average of the
     generator weights (tf.contrib.opt.MovingAverageOptimizer).  ``percentage`` in [0, log2(upRes)] is fed per
-    step (3.0 = the final 8x stage).  The temporal discriminator branch is not built."""
+    step (3.0 = the final 8x stage)."""
 
     def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
@@ -856,8 +856,6 @@ class Trainer8x(object):
             self.y_in = G.placeholder([None, cfg.n_output], name="y_in")
             x_in = self.x
         else:       # later networks: `y` carries (target, previous pass) as two channels (:1041-1060)
-            if use_tempo:
-                raise NotImplementedError("temporal branch of the second / third network")
             self.y2 = G.placeholder([None, cfg.n_output * 2], name="y")
             x_in, self.y_in = nets8x.later_network_input(self.x, self.y2, cfg)
         self.gen_y = nets8x.growing_gen(x_in, self.percentage, cfg, train=True, currentUpres=self.currentUpres)
@@ -870,7 +868,12 @@ class Trainer8x(object):
         self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
         if use_tempo:
             self.x_t = G.placeholder([None, cfg.n_input], name="x_t")
-            self.gen_ts = nets8x.growing_gen(self.x_t, self.percentage, cfg, reuse=True, train=True,
+            if cfg.upsampling_mode == 2:
+                self.y_t2, x_t_in = None, self.x_t
+            else:   # (:1171-1172) previous pass of the three frames = channel 1 of y_t
+                self.y_t2 = G.placeholder([None, cfg.n_output * 2], name="yt")
+                x_t_in, _ = nets8x.later_network_input(self.x_t, self.y_t2, cfg)
+            self.gen_ts = nets8x.growing_gen(x_t_in, self.percentage, cfg, reuse=True, train=True,
                                              currentUpres=self.currentUpres)
             tk = dict(cfg=cfg, n_t_channels=self.n_t, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
             self.t_fake = G.placeholder([None, cfg.n_output * self.n_t], name="t_fake")
@@ -960,6 +963,7 @@ class Trainer8x(object):
         """advection look-up at the CURRENT stage's resolution (the positions come at tileSizeLow * 2^stage):
         generated frames are nearest-downsampled to it, resampled, and resized back (:1178-1200)"""
         th = self.cfg.tileSizeHigh
+        frames = frames.reshape(frames.shape[0], -1)
         cur = int(round(math.sqrt(frames.shape[1])))
         if self.adv_flag:
             pos = torch.as_tensor(y_pos, dtype=torch.float32, device=frames.device)
@@ -980,7 +984,11 @@ class Trainer8x(object):
         dev = self.sess.device
         xts = torch.as_tensor(batch_xts, dtype=torch.float32, device=dev)
         yts = torch.as_tensor(batch_yts, dtype=torch.float32, device=dev)
-        gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.percentage: percentage})[0]
+        if self.y_t2 is None:
+            gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.percentage: percentage})[0]
+        else:       # rows of (target, previous pass) pairs: the real frames are channel 0 (:1218-1219)
+            gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.y_t2: yts, self.percentage: percentage})[0]
+            yts = yts.reshape(-1, self.cfg.n_output, 2)[:, :, 0].contiguous()
         fake = self._frames_as_channels(gen_ts, batch_y_pos)
         real = self._frames_as_channels(yts, batch_y_pos)
         gen_s, disc_s = self.sess.run([self.gen_s, self.disc_s], {self.t_fake: fake, self.t_real: real,

@@ -162,10 +162,9 @@ def tempo_losses_8x(p, batch_xts, batch_yts, batch_y_pos, tile_low, channels, pe
     return L
 
 
-def later_nets_losses_8x(p, batch_xs, batch_ys2, tile_low, channels, percentage=3.0, lerp_factor=None, filter_pn=True,
-                         wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, lambda_l1=1.0):
-    """second / third network (upsampling_mode 1 / 3, use_res_net, not firstNNArch; multipassGAN-8x.py
-    :1041-1060): y holds (target, previous pass); no resolution change inside generator or critic"""
+def later_gen(p, batch_xs, batch_ys2, tile_low, channels, percentage):
+    """generator of the second / third network on (x, y = (target, previous pass)) rows (multipassGAN-8x.py
+    :1041-1047, growing_gen :598-700 with use_res_net and not firstNNArch) -> (gen_y, target), NCHW"""
     th = tile_low * 8
     xs = np.asarray(batch_xs, np.float32).reshape(-1, tile_low, tile_low, channels)
     y2 = torch.tensor(np.asarray(batch_ys2), dtype=DT).reshape(-1, th, th, 2)
@@ -184,23 +183,67 @@ def later_nets_losses_8x(p, batch_xs, batch_ys2, tile_low, channels, percentage=
         x_g = res_block(p, sc, x_g, "second")
         dens = conv(p, sc + "g_cdensOut%d" % up, x_g, None, gain=1) + x_in[:, 0:1]
         old = lerp(old, dens, percentage - (j - 1))
-    gen_y = old
+    return old, target
+
+
+def later_critic(p, scope, c, inp, percentage):
+    """critic of the second / third network (no pooling: every block at tileSizeHigh; growing_disc :786-866 and
+    growing_disc_tempo :869-923 with upsampling_mode 1 / 3, not firstNNArch); scope "spatial-disc/" with
+    c = "d", or "tempo-disc/" with c = "t" """
+    x = conv(p, scope + "%s_cfromDensity8" % c, inp)
+    for j in range(3, 0, -1):
+        blk = scope + "%sBlock%d/" % (c, 2 ** j)
+        x1 = conv(p, blk + "%s_cA%d" % (c, 2 ** j), x, "lrelu")
+        x2 = conv(p, blk + "%s_cB%d" % (c, 2 ** j), x1, "lrelu")
+        oldd = conv(p, scope + "%s_cfromDensity%d" % (c, 2 ** (j - 1)), inp)
+        x = lerp(oldd, x2, percentage - (j - 1))
+    x1 = conv(p, scope + "%s_cA1" % c, x, "lrelu")
+    x2 = conv(p, scope + "%s_cB1" % c, x1)
+    flat = x2.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
+    w = p[scope + "%s_l61/weight" % c]
+    return flat @ (w * _ws(w, 1.0)) + p[scope + "%s_l61/bias" % c]
+
+
+def tempo_later_nets_losses_8x(p, batch_xts, batch_yts2, batch_y_pos, tile_low, channels, percentage=3.0,
+                               lerp_factor=None, wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0):
+    """temporal critic of the second / third network (multipassGAN-8x.py:1167-1300 with upsampling_mode 1 / 3):
+    the generator runs on the three coherent frames (previous pass = channel 1 of y_t), the real triple is
+    channel 0 of y_t, both advected by the tensorResample look-up at tileSizeHigh"""
+    from .train_ref import tensor_resample
+    th = tile_low * 8
+    gen_ts, target = later_gen(p, batch_xts, batch_yts2, tile_low, channels, percentage)
+
+    def pack(frames_nhwc):
+        v = tensor_resample(frames_nhwc, batch_y_pos, True)
+        return v.reshape(-1, 3, th * th).permute(0, 2, 1)                  # [B, n_output, 3]
+
+    fake = pack(gen_ts.permute(0, 2, 3, 1))
+    real = pack(target.permute(0, 2, 3, 1))
+    to_img = lambda v: v.reshape(-1, th, th, 3).permute(0, 3, 1, 2)       # noqa: E731
+    gen_s = later_critic(p, "tempo-disc/", "t", to_img(fake), percentage)
+    disc_s = later_critic(p, "tempo-disc/", "t", to_img(real), percentage)
+    t_disc_loss = (-disc_s).mean() * weight_dld + gen_s.mean()
+    if lerp_factor is not None:
+        lf = torch.tensor(np.asarray(lerp_factor), dtype=DT).reshape(-1, 1, 1)
+        y_gp = (lf * real + (1 - lf) * fake.detach()).requires_grad_(True)
+        t_out = later_critic(p, "tempo-disc/", "t", to_img(y_gp), percentage)
+        (g,) = torch.autograd.grad(t_out.mean(), y_gp, create_graph=True)
+        norm = torch.sqrt(((g + 1e-4) ** 2).sum(dim=1))
+        t_disc_loss = t_disc_loss + (disc_s ** 2).mean() * wgan_epsilon + (wgan_lambda * (norm - wgan_target) ** 2).mean()
+    return {"t_disc_loss": t_disc_loss, "g_loss_t": (-gen_s).mean()}
+
+
+def later_nets_losses_8x(p, batch_xs, batch_ys2, tile_low, channels, percentage=3.0, lerp_factor=None, filter_pn=True,
+                         wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, lambda_l1=1.0):
+    """second / third network (upsampling_mode 1 / 3, use_res_net, not firstNNArch; multipassGAN-8x.py
+    :1041-1060): y holds (target, previous pass); no resolution change inside generator or critic"""
+    th = tile_low * 8
+    xs = np.asarray(batch_xs, np.float32).reshape(-1, tile_low, tile_low, channels)
+    gen_y, target = later_gen(p, batch_xs, batch_ys2, tile_low, channels, percentage)
 
     def critic(high):
-        d = "spatial-disc/"
         low = torch.tensor(O.resize_nearest_tf1(xs[..., :1], th, th), dtype=DT).permute(0, 3, 1, 2)
-        inp = torch.cat([low, high], dim=1)
-        x = conv(p, d + "d_cfromDensity8", inp)
-        for j in range(3, 0, -1):
-            x1 = conv(p, d + "dBlock%d/d_cA%d" % (2 ** j, 2 ** j), x, "lrelu")
-            x2 = conv(p, d + "dBlock%d/d_cB%d" % (2 ** j, 2 ** j), x1, "lrelu")
-            oldd = conv(p, d + "d_cfromDensity%d" % (2 ** (j - 1)), inp)
-            x = lerp(oldd, x2, percentage - (j - 1))
-        x1 = conv(p, d + "d_cA1", x, "lrelu")
-        x2 = conv(p, d + "d_cB1", x1)
-        flat = x2.permute(0, 2, 3, 1).reshape(x2.shape[0], -1)
-        w = p[d + "d_l61/weight"]
-        return flat @ (w * _ws(w, 1.0)) + p[d + "d_l61/bias"]
+        return later_critic(p, "spatial-disc/", "d", torch.cat([low, high], dim=1), percentage)
 
     disc, gen = critic(target), critic(gen_y)
     L = {"gen_y": gen_y}

@@ -190,6 +190,48 @@ def test_8x_training_driver(tmp_path):
     _run("multipassGAN-out.py", oargs, str(tmp_path))
 
 
+def test_8x_training_driver_second_network(tmp_path):
+    """example_run_training.py's second command (reduced sizes): upsamplingMode 1, upsampledData 1 -- slices along
+    the x axis, the first network's output volumes (density_low_t0000_2x2_%04d.uni) as the extra high-res input
+    channel, residual generator / critics without resolution changes, spatial + temporal WGAN-GP critics"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import checkpoint, uniio
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, frames, up = 8, 5, 8
+    d = tmp_path / "data" / "sim_1007"
+    d.mkdir(parents=True)
+    (tmp_path / "models").mkdir()
+    for f in range(frames):
+        v = synthetic_volume(sim, 4, f)
+        uniio.writeUni(str(d / ("density_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim), v[..., 0:1] + 0.05)
+        uniio.writeUni(str(d / ("velocity_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim, vec3=True), v[..., 1:4])
+        hdr = uniio.make_header(sim * up, sim * up, sim * up)
+        uniio.writeUni(str(d / ("density_high_%04d.uni" % f)), hdr, synthetic_volume(sim * up, 1, 800 + f) + 0.05)
+        uniio.writeUni(str(d / ("density_low_t0000_2x2_%04d.uni" % f)), hdr, synthetic_volume(sim * up, 1, 900 + f) + 0.05)
+    args = ["randSeed", 9631119, "upRes", 8, "use_res_net", 1, "batchNorm", 0, "pixelNorm", 1, "out", 0, "pretrain", 0,
+            "pretrainDisc", 0, "tileSize", 4, "simSize", sim, "use_LSGAN", 0, "use_wgan_gp", 1, "lambda", 1.0, "lambda2", 0.0,
+            "discRuns", 1, "genRuns", 1, "alwaysSave", 1, "fromSim", 1007, "toSim", 1007, "outputInterval", 3, "genTestImg", -1,
+            "dropout", 0.5, "dataDim", 2, "batchSize", 3, "useVelocities", 1, "useVorticities", 0, "useK_Eps_Turb", 0,
+            "useFlags", 0, "gif", 0, "genModel", "gen_resnet", "discModel", "disc_binclass",
+            "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/", "lambda_t", 1.0,
+            "lambda_t_l2", 0.0, "frame_max", 2, "frame_min", 0, "data_fraction", 1.0, "adv_flag", 1, "adv_mode", 0,
+            "dataAugmentation", 1, "premadeTiles", 0, "rot", 1, "minScale", 0.85, "maxScale", 1.15, "flip", 1, "decayLR", 1,
+            "adam_beta1", 0.0, "adam_beta2", 0.99, "learningRate", 0.0001, "lossScaling", 1, "stageIter", 1, "decayIter", 3,
+            "maxFms", 32, "startFms", 32, "filterSize", 5, "outNNTestNo", 0, "upsamplingMode", 1, "upsampledData", 1,
+            "upsampleMode", 1, "usePixelShuffle", 0, "addBicubicUpsample", 1, "startingIter", 0, "useVelInTDisc", 0, "gpu", 0,
+            "load_model_test", -1, "load_model_no", -1, "saveInterval", 100]
+    out = _run("multipassGAN-8x.py", args, str(tmp_path))
+    # the growing schedule of the reference (:1885-1975) only re-arms the fade-in at a resolution change, which never
+    # comes for currentUpres = 8: with stageIter 1 the blend value stays at 2.0, as in the reference's own run
+    assert "TRAINING FINISHED" in out and "blending percentage: 2.000000" in out and "NEW UPRES" not in out
+    test_dir = tmp_path / "models" / "test_0000"
+    last = checkpoint.load(str(test_dir / "model_0000.ckpt"))
+    assert all(np.isfinite(v).all() for v in last.values())
+    # the second network's variables: 5-channel input (previous pass + d, vx, vy, vz), critics with the _cA1 / _cB1 head
+    assert last["generator/g_cA_1/weight"].shape[2] == 5
+    assert "tempo-disc/t_cB1/weight" in last and "spatial-disc/d_cB1/weight" in last
+
+
 def test_4x_training_driver_second_network(tmp_path):
     """`out 0 upsamplingMode 1 upsampledData 1`: the second 4x network trains on slices along x of the zoomed
     volumes whose density channel is the first network's output (density_low_2x2_%04d.uni)"""

@@ -193,3 +193,56 @@ def test_second_network_training_step():
         assert math.sqrt(tot[0] / tot[1]) < lim, math.sqrt(tot[0] / tot[1])
     d, g = tr.train_step(xs, ys2, 3.0)
     assert np.isfinite(float(d)) and np.isfinite(float(g))
+
+
+def test_second_network_temporal_branch():
+    """temporal critic of the second / third network (multipassGAN-8x.py:1167-1300, upsampling_mode 1): generator on
+    the three coherent frames with the previous pass from channel 1 of y_t, real frames = channel 0, critic without
+    pooling; tiles and advection positions from the TileCreator ('d,d' high layout, as the training script feeds it)"""
+    import contextlib
+    import io
+    import random
+    from mpgan_amd import tilecreator_t as tc
+    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.train import Trainer8x
+    tile, C = 4, 4
+    rng = np.random.default_rng(43)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tiCr = tc.TileCreator(tileSizeLow=tile, simSizeLow=8, upres=8, dim=2, dim_t=3, densityMinimum=0.0,
+                              channelLayout_low="d,vx,vy,vz", channelLayout_high="d,d")
+        tiCr.addData(rng.random((4, 1, 8, 8, 12)).astype(np.float32), rng.random((4, 1, 64, 64, 6)).astype(np.float32))
+    random.seed(5)
+    xts, yts, ypos = tiCr.selectRandomTempoTiles(6, True, False, n_t=3, dt=0.5)
+    assert yts.shape[1] == 32 * 32 * 2
+    cfg = Cfg8x(tileSizeLow=tile, upRes=8, n_inputChannels=C, upsampling_mode=1, first_nn_arch=False, filterSize=5,
+                start_fms=32, max_fms=32)
+    tr = Trainer8x(cfg, device=DEV, seed=4, use_tempo=True)
+    ps = ParamSource(seed=4)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in tr.graph.variables.items()}
+    with torch.no_grad():
+        for n, t in tr.sess.params.items():
+            t.copy_(torch.as_tensor(params[n], device=DEV))
+    p = TR.to_params(params)
+    lf_t = rng.random((2, 1)).astype(np.float32)
+    L = tr.tempo_losses(xts, yts, ypos, 2.7, lf_t)
+    Lr = TR8.tempo_later_nets_losses_8x(p, xts, yts, ypos, tile, C, 2.7, lf_t)
+    for k in ("t_disc_loss", "g_loss_t"):
+        a, b = float(L[k].detach()), float(Lr[k].detach())
+        assert abs(a - b) <= 3e-4 * max(abs(b), 1e-2), (k, a, b)
+    gt = torch.autograd.grad(L["t_disc_loss"], tr.opt_t.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["g_loss_t"], tr.opt_g.params, allow_unused=True)
+    rt = {k: v for k, v in TR.grads(Lr["t_disc_loss"], p, "t_").items() if k.startswith("tempo-disc")}
+    rg = TR.grads(Lr["g_loss_t"], p, "g_")
+    assert sorted(rt) == tr.opt_t.names
+    for names, got, want in ((tr.opt_t.names, gt, rt), (tr.opt_g.names, gg, rg)):
+        for nme, g in zip(names, got):
+            w = want[nme]
+            gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
+            if np.abs(w).max() == 0.0:
+                assert np.abs(gnp).max() < 1e-7, nme
+                continue
+            assert rel(gnp, w) < 5e-3, (nme, rel(gnp, w))
+    xs = rng.random((2, tile * tile * C)).astype(np.float32)
+    ys2 = rng.random((2, 32 * 32 * 2)).astype(np.float32)
+    d, g = tr.train_step(xs, ys2, 3.0, tempo=(xts, yts, ypos))
+    assert np.isfinite(float(d)) and np.isfinite(float(g))
