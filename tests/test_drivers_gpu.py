@@ -190,10 +190,12 @@ def test_8x_training_driver(tmp_path):
     _run("multipassGAN-out.py", oargs, str(tmp_path))
 
 
-def test_8x_training_driver_second_network(tmp_path):
+@pytest.mark.parametrize("mode,prev", [(1, "density_low_t0000_2x2_%04d.uni"), (3, "density_low_t0000_1x1_%04d.uni")])
+def test_8x_training_driver_later_networks(tmp_path, mode, prev):
     """example_run_training.py's second command (reduced sizes): upsamplingMode 1, upsampledData 1 -- slices along
     the x axis, the first network's output volumes (density_low_t0000_2x2_%04d.uni) as the extra high-res input
-    channel, residual generator / critics without resolution changes, spatial + temporal WGAN-GP critics"""
+    channel, residual generator / critics without resolution changes, spatial + temporal WGAN-GP critics; and the
+    third network's variant (upsamplingMode 3: slices along y, ..._1x1_... volumes)"""
     import mpgan_amd  # noqa: F401
     from mpgan_amd import checkpoint, uniio
     from mpgan_amd.synthetic import synthetic_volume
@@ -207,7 +209,7 @@ def test_8x_training_driver_second_network(tmp_path):
         uniio.writeUni(str(d / ("velocity_low_%04d.uni" % f)), uniio.make_header(sim, sim, sim, vec3=True), v[..., 1:4])
         hdr = uniio.make_header(sim * up, sim * up, sim * up)
         uniio.writeUni(str(d / ("density_high_%04d.uni" % f)), hdr, synthetic_volume(sim * up, 1, 800 + f) + 0.05)
-        uniio.writeUni(str(d / ("density_low_t0000_2x2_%04d.uni" % f)), hdr, synthetic_volume(sim * up, 1, 900 + f) + 0.05)
+        uniio.writeUni(str(d / (prev % f)), hdr, synthetic_volume(sim * up, 1, 900 + f) + 0.05)
     args = ["randSeed", 9631119, "upRes", 8, "use_res_net", 1, "batchNorm", 0, "pixelNorm", 1, "out", 0, "pretrain", 0,
             "pretrainDisc", 0, "tileSize", 4, "simSize", sim, "use_LSGAN", 0, "use_wgan_gp", 1, "lambda", 1.0, "lambda2", 0.0,
             "discRuns", 1, "genRuns", 1, "alwaysSave", 1, "fromSim", 1007, "toSim", 1007, "outputInterval", 3, "genTestImg", -1,
@@ -217,7 +219,7 @@ def test_8x_training_driver_second_network(tmp_path):
             "lambda_t_l2", 0.0, "frame_max", 2, "frame_min", 0, "data_fraction", 1.0, "adv_flag", 1, "adv_mode", 0,
             "dataAugmentation", 1, "premadeTiles", 0, "rot", 1, "minScale", 0.85, "maxScale", 1.15, "flip", 1, "decayLR", 1,
             "adam_beta1", 0.0, "adam_beta2", 0.99, "learningRate", 0.0001, "lossScaling", 1, "stageIter", 1, "decayIter", 3,
-            "maxFms", 32, "startFms", 32, "filterSize", 5, "outNNTestNo", 0, "upsamplingMode", 1, "upsampledData", 1,
+            "maxFms", 32, "startFms", 32, "filterSize", 5, "outNNTestNo", 0, "upsamplingMode", mode, "upsampledData", 1,
             "upsampleMode", 1, "usePixelShuffle", 0, "addBicubicUpsample", 1, "startingIter", 0, "useVelInTDisc", 0, "gpu", 0,
             "load_model_test", -1, "load_model_no", -1, "saveInterval", 100]
     out = _run("multipassGAN-8x.py", args, str(tmp_path))
