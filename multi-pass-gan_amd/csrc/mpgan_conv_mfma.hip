@@ -44,6 +44,7 @@ struct SegArgs {
     int ni_img;           // image DMA instructions per thread per chunk
     int sw_hi, sw_lo;     // F16F8: E8M0 scale words (replicated bytes) of the fp8 weight planes
     int direct;           // F16F8, 1x1 over >= 2 groups: B fragments straight from memory, K runs over groups
+    int tp;               // F16F8: tap slots per channel group (kh*kw, or rounded up to 8 when below 16)
 };
 
 struct ConvArgs {
@@ -62,6 +63,7 @@ struct ConvArgs {
     const float* in_amax; // inputs were multiplied by pow2_scale(*in_amax): the accumulators are divided by it
     const char* zeros;    // >= 16 zero bytes (source of out-of-image pixels)
     int img_bytes;        // bytes of one LDS image buffer (max over segments)
+    int tap_bytes;        // F16F8: bytes of the two tap-offset tables at the start of LDS
     int tiles_x, tiles_y;
     int dbg;              // development probes: 1 skip K loop, 2 skip stores
 };
@@ -428,7 +430,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
     constexpr int NI = P::NI, R = P::R, D = P::D, THREADS = WAVES * 64;
 
     int* tapoff = reinterpret_cast<int*>(smem);
-    char* img_lds = smem + TAPOFF_BYTES;
+    int* tap16 = reinterpret_cast<int*>(smem + (a.tap_bytes >> 1));
+    char* img_lds = smem + a.tap_bytes;
     char* w_lds = img_lds + 2 * a.img_bytes;
 
     const int tid = threadIdx.x;
@@ -543,18 +546,27 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             __syncthreads();
             continue;
         }
+        // K is ONE stream of tap slots over the channel groups of the segment: slot q = (group q / tp, tap q % tp),
+        // eight slots per weight stage, so a stage may finish one group and start the next (25 taps x 16 groups =
+        // 50 full stages instead of 16 x 4 with 7 empty slots each).  Group g's halo image lives in LDS buffer
+        // g & 1; the offset tables carry the buffer with the tap.
         const int T = sg.kh * sg.kw;
+        const int G = sg.nchunks;
+        const int NS = sg.sc;
         const int plane_b = sg.np * 16;
         const int ppg = sg.np >> 6;
 
-        for (int q = tid; q < sg.sc * 8; q += THREADS) {
+        for (int q = tid; q < NS * 8; q += THREADS) {
+            const int g = q / sg.tp;
+            const int t = q - g * sg.tp;
             int off = 0;
-            if (q < T) {
-                const int dy = q / sg.kw;
-                const int dx = q - dy * sg.kw;
-                off = (dy * sg.iw + dx) * 16;
+            if (g < G && t < T) {
+                const int dy = t / sg.kw;
+                const int dx = t - dy * sg.kw;
+                off = (g & 1) * a.img_bytes + (dy * sg.iw + dx) * 16;
             }
-            tapoff[q] = off;
+            tapoff[q] = off;                                                        // fp8 order: slot
+            tap16[(q >> 3) * 8 + (q & 1) * 4 + ((q & 7) >> 1)] = off;             // fp16 order: [stage][half][k-step]
         }
         int pixb[PT];
 #pragma unroll
@@ -578,9 +590,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 dma16(src, buf + pc * 1024);
             }
         };
-        const int total_stages = sg.nchunks * sg.sc;
         auto dma_stage = [&](int stage) {
-            const int sidx = stage < total_stages ? stage : total_stages - 1;
+            const int sidx = stage < NS ? stage : NS - 1;
             const char* src = sg.w + (size_t)sidx * WSTAGE + tid * 16;
             char* dst = w_lds + (stage % R) * WSTAGE + wave_u * 1024;
 #pragma unroll
@@ -590,57 +601,78 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
         dma_image(0);
 #pragma unroll
         for (int d = 0; d < D; ++d) dma_stage(d);
+        int g_next = 1;                                  // next group image to fetch
+        const char* img = img_lds;
 
-        for (int ch = 0; ch < sg.nchunks; ++ch) {
-            if (sg.sc < D) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const char* img = img_lds + (ch & 1) * a.img_bytes;
-            for (int st = 0; st < sg.sc; ++st) {
-                const int gst = ch * sg.sc + st;
-                wait_dma_and_barrier<(D - 1) * NI>();
-                if (st == 0 && ch + 1 < sg.nchunks) dma_image(ch + 1);
-                dma_stage(gst + D);
-                const char* wb = w_lds + (gst % R) * WSTAGE;
-                const int tap0 = st * 8;
-                // ---- main product: fp16, two taps per k-step; k-steps past the last tap are skipped ----
+        for (int st = 0; st < NS; ++st) {
+            // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
+            // with stage st-1
+            wait_dma_and_barrier<(D - 1) * NI>();
+            // tap offsets of the whole stage in two 16-byte reads, before this stage's DMAs are issued (the compiler
+            // orders LDS reads behind pending LDS-DMA writes)
+            const int4 o16 = *reinterpret_cast<const int4*>(tap16 + (st * 2 + hh) * 4);
+            const int4 o8 = *reinterpret_cast<const int4*>(tapoff + st * 8 + 4 * hh);
+            asm volatile("" ::"v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w), "v"(o8.x), "v"(o8.y), "v"(o8.z), "v"(o8.w));
+            // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
+            // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
+            if (g_next < G && st * 8 >= (g_next - 1) * sg.tp) {
+                dma_image(g_next);
+                ++g_next;
+            }
+            dma_stage(st + D);
+            const char* wb = w_lds + (st % R) * WSTAGE;
+            const int to16[4] = {o16.x, o16.y, o16.z, o16.w};
+            const int to8[4] = {o8.x, o8.y, o8.z, o8.w};
+            {
+                // software-pipelined by hand: every fragment is read from LDS two MFMA groups (one group = the PT
+                // MFMAs of one weight fragment) before the group that consumes it
+                half8 bq[3][PT], aq[3];     // (with one cout tile, two groups ahead is two k-steps ahead)
+                v8i b8_hi[PT], b8_lo[PT], wq[2][2];
+                auto read_group = [&](int g) {            // operands of fp16 group g = k-step * NT + cout tile
+                    const int j = g / NT, nt = g % NT;
+                    if (nt == 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (tap0 + 2 * j < T) {
-                        const int toff = tapoff[tap0 + 2 * j + hh];
-                        half8 b_hi[PT];
-#pragma unroll
-                        for (int pt = 0; pt < PT; ++pt) b_hi[pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + toff);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
-#pragma unroll
-                            for (int pt = 0; pt < PT; ++pt)
-                                acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[pt], acc[pt][nt], 0, 0, 0);
-                        }
+                        for (int pt = 0; pt < PT; ++pt)
+                            bq[j % 3][pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + to16[j]);
                     }
-                }
-                // ---- corrections: lane (pixel r, half hh) holds taps tap0 + 4*hh + {0..3} x 8 channels ----
-                v8i b8_hi[PT], b8_lo[PT];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int toff = tapoff[tap0 + 4 * hh + i];
+                    aq[g % 3] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+                };
+                auto read_w8 = [&](int nt) {
+                    wq[nt & 1][0] = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
+                    wq[nt & 1][1] = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+                };
+                auto read_b8 = [&](int i) {
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
-                        const int4 v = *reinterpret_cast<const int4*>(img + plane_b + pixb[pt] + toff);
+                        const int4 v = *reinterpret_cast<const int4*>(img + plane_b + pixb[pt] + to8[i]);
                         b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
                         b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
                     }
+                };
+                read_group(0);
+                read_group(1);
+#pragma unroll
+                for (int g = 0; g < 4 * NT; ++g) {
+                    if (g + 2 < 4 * NT) read_group(g + 2);
+                    // the correction operands ride behind the last fp16 groups
+                    if (g >= 4 * NT - 4) read_b8(g - (4 * NT - 4));
+                    if (g == 4 * NT - 2) read_w8(0);
+                    if (g == 4 * NT - 1 && NT > 1) read_w8(1);
+                    const int j = g / NT, nt = g % NT;
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % 3], bq[j % 3][pt], acc[pt][nt], 0, 0, 0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const v8i w8_hi = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
-                    const v8i w8_lo = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][0], b8_lo[pt], acc[pt][nt], 0, 0, 0,
                                                                                    sg.sw_hi, 0, sa_lo);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_lo, b8_hi[pt], acc[pt][nt], 0, 0, 0,
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][1], b8_hi[pt], acc[pt][nt], 0, 0, 0,
                                                                                    sg.sw_lo, 0, sa_hi);
                     }
+                    if (nt + 2 < NT) read_w8(nt + 2);
                 }
             }
         }
@@ -654,7 +686,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 //   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][64 lanes][32 x fp8 hi]  |  [NT][64 lanes][32 x fp8 lo]
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                        int cin, int cout, float wscale, const float* __restrict__ cscale,
-                                       int NT, int nchunks, int sc, float s_hi, float s_lo, int fold,
+                                       int NT, int nchunks, int sc, float s_hi, float s_lo, int fold, int tp,
                                        char* __restrict__ out) {
     // fold (direct 1x1 segments): one chunk, the "taps" of a macro-step are 8 consecutive channel groups
     const int T = kh * kw;
@@ -667,14 +699,20 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int 
     long rest = idx >> 12;
     const int nt = rest % NT; rest /= NT;
     const int st = rest % sc;
-    const int c = rest / sc;                         // channel group
+    const int c = rest / sc;                         // (fold / legacy) chunk; 0 in the flat layout
     const int r = lane & 31, hh = lane >> 5;
     const int co = nt * 32 + r;
     const size_t stage_b = (size_t)8 * NT * 1024;
     char* base = out + ((size_t)c * sc + st) * stage_b;
     auto weight = [&](int tap, int j) -> float {
-        const int chn = fold ? tap * 8 + j : c * 8 + j;
+        // flat layout (tp > 0): `tap` is the slot within the stream, slot = group * tp + tap
+        int chn = fold ? tap * 8 + j : c * 8 + j;
         if (fold) tap = 0;
+        else if (tp > 0) {
+            const int g = tap / tp;
+            tap -= g * tp;
+            chn = g * 8 + j;
+        }
         if (tap >= T || chn >= cin || co >= cout) return 0.f;
         float v = w[((size_t)tap * cin_total + c_off + chn) * cout + co] * wscale;
         if (cscale != nullptr) v *= cscale[co];
@@ -963,7 +1001,7 @@ Shape pipe_shape(int nt, int prec) {
 }
 
 struct SegShape {
-    int cgc, nchunks, sc, np, ni_img, img_bytes, direct;
+    int cgc, nchunks, sc, np, ni_img, img_bytes, direct, tp;
 };
 
 // groups per chunk: two when that removes the half-empty k-step of an odd tap count and the
@@ -977,6 +1015,7 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
     const int ring = ps.r * ps.ks * nt * 1024 * npl;
     SegShape s;
     s.direct = 0;
+    s.tp = 0;
     s.np = np;
     s.cgc = 1;
     if (cg >= 2 && ((kh * kw) & 1)) {
@@ -997,8 +1036,10 @@ bool f8_supported(int nt) { return nt >= 1 && nt <= 4; }
 int f8_waves(int nt) { return nt == 1 ? 4 : 8; }
 
 SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
+    // nchunks = channel groups (one LDS halo image each), sc = weight stages of the whole segment
     SegShape s;
     s.direct = 0;
+    s.tp = 0;
     if (kh == 1 && kw == 1 && cin > 8 && nt <= 2) {   // conv_mfma_f8_kernel's direct path: K over channel groups
         s.direct = 1; s.cgc = 1; s.np = 0; s.ni_img = 0; s.img_bytes = 0;
         s.nchunks = 1;
@@ -1013,7 +1054,12 @@ SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
     s.ni_img = (pieces + waves - 1) / waves;
     s.img_bytes = s.ni_img * waves * 1024;
     s.nchunks = (cin + 7) / 8;
-    s.sc = (kh * kw + 7) / 8;
+    // tap slots per group: the taps themselves when a group spans >= 2 stages; below that padded to 8, 12 or 16 so
+    // that the image of group g+1 (issued once no stage touches group g-1) has >= 1 stage of flight before its
+    // first slot: floor(tp (g+1) / 8) - ceil(tp g / 8) >= 1 for every g
+    const int T = kh * kw;
+    s.tp = T >= 16 ? T : T <= 8 ? 8 : T <= 12 ? 12 : 16;
+    s.sc = (s.nchunks * s.tp + 7) / 8;
     return s;
 }
 
@@ -1108,7 +1154,7 @@ static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec) {
     if (prec == MPG_PREC_F16F8) {
         if (!f8_supported(nt)) return 0;
         const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
-        return (size_t)ss.nchunks * ss.sc * 8 * nt * 1024;
+        return (size_t)ss.sc * 8 * nt * 1024;
     }
     if (prec != MPG_PREC_F16X1 && prec != MPG_PREC_F16X3) return 0;
     const Shape ps = pipe_shape(nt, prec);
@@ -1133,10 +1179,10 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
     if (prec == MPG_PREC_F16F8) {
         MPG_REQUIRE(w_exp >= -100 && w_exp <= 100, "mpg_conv_pack_weights: w_exp %d out of range", w_exp);
         const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
-        const long total = (long)ss.nchunks * ss.sc * nt * 64 * 64;
+        const long total = (long)ss.sc * nt * 64 * 64;
         hipLaunchKernelGGL(pack_weights_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ss.nchunks, ss.sc,
-                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), ss.direct, (char*)out);
+                           w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, 1, ss.sc,
+                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), ss.direct, ss.tp, (char*)out);
         if (small_layer(cin, cout))
             hipLaunchKernelGGL(pack_small_kernel, dim3((kh * kw * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio,
                                kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
@@ -1215,7 +1261,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
 
     ConvArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cout = d->cout; a.nseg = d->nseg;
-    int max_img = 0;
+    int max_img = 0, max_slots = 0;
     for (int s = 0; s < d->nseg; ++s) {
         const mpg_conv_seg& g = d->seg[s];
         MPG_REQUIRE(g.x && g.wpack, "mpg_conv2d_fused: segment %d null pointer", s);
@@ -1227,7 +1273,8 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
                     "mpg_conv2d_fused: segment %d: %dx%d not divisible by upsample %d", s, d->h, d->w, 1 << g.up_log2);
         MPG_REQUIRE((((uintptr_t)g.x) & 15) == 0 && (((uintptr_t)g.wpack) & 15) == 0, "mpg_conv2d_fused: segment %d misaligned", s);
         const SegShape ss = f8 ? seg_shape_f8(g.kh, g.kw, g.cin, nt) : seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
-        MPG_REQUIRE((f8 ? ss.sc * 8 : ss.sc * ps.ks * 2) <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
+        MPG_REQUIRE(f8 || ss.sc * ps.ks * 2 <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
+        if (f8 && !ss.direct) max_slots = ss.sc * 8 > max_slots ? ss.sc * 8 : max_slots;
         SegArgs& o = a.seg[s];
         o.x = (const char*)g.x; o.w = (const char*)g.wpack;
         o.cg_seg = (g.cin + 7) / 8; o.cg_total = g.cgroups; o.g_off = g.g_off;
@@ -1238,6 +1285,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         o.hs = d->h >> g.up_log2; o.ws = d->w >> g.up_log2;
         o.np = ss.np; o.ni_img = ss.ni_img;
         o.direct = ss.direct;
+        o.tp = ss.tp;
         MPG_REQUIRE(!ss.direct || (size_t)(d->h >> g.up_log2) * (d->w >> g.up_log2) * 16 * 16 < ((size_t)1 << 31),
                     "mpg_conv2d_fused: segment %d: %dx%d too large for the 1x1 path (32-bit group offsets)", s, d->h, d->w);
         o.sw_hi = o.sw_lo = 0;
@@ -1267,7 +1315,10 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(nblk < (1L << 31), "mpg_conv2d_fused: grid too large");
     const int waves = f8 ? f8_waves(nt) : 4;
     const size_t ring = f8 ? (size_t)3 * 8 * nt * 1024 : (size_t)ps.r * ps.ks * nt * 1024 * npl;
-    const size_t lds_loop = TAPOFF_BYTES + 2 * (size_t)max_img + ring;
+    // F16F8: two tap-offset tables (slot order, fp16 k-step order) of max_slots entries, 1 KiB granules
+    a.tap_bytes = f8 ? 2 * (((max_slots * 4 + 1023) / 1024) * 1024) : TAPOFF_BYTES;
+    if (a.tap_bytes < TAPOFF_BYTES) a.tap_bytes = TAPOFF_BYTES;
+    const size_t lds_loop = (size_t)a.tap_bytes + 2 * (size_t)max_img + ring;
     const size_t lds_epi = TAPOFF_BYTES + (size_t)waves * 32 * (nt * 32 + 4) * sizeof(float);
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_fused: LDS budget %zu exceeds 160 KiB", lds);
