@@ -27,6 +27,9 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef MPG_AH
+#define MPG_AH 2
+#endif
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
@@ -626,16 +629,17 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             {
                 // software-pipelined by hand: every fragment is read from LDS two MFMA groups (one group = the PT
                 // MFMAs of one weight fragment) before the group that consumes it
-                half8 bq[3][PT], aq[3];     // (with one cout tile, two groups ahead is two k-steps ahead)
+                constexpr int AH = MPG_AH;    // read-ahead distance in MFMA groups
+                half8 bq[AH + 1][PT], aq[AH + 1];   // (with one cout tile, AH groups ahead is AH k-steps ahead)
                 v8i b8_hi[PT], b8_lo[PT], wq[2][2];
                 auto read_group = [&](int g) {            // operands of fp16 group g = k-step * NT + cout tile
                     const int j = g / NT, nt = g % NT;
                     if (nt == 0) {
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt)
-                            bq[j % 3][pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + to16[j]);
+                            bq[j % (AH + 1)][pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + to16[j]);
                     }
-                    aq[g % 3] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+                    aq[g % (AH + 1)] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
                 };
                 auto read_w8 = [&](int nt) {
                     wq[nt & 1][0] = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
@@ -649,11 +653,11 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                         b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
                     }
                 };
-                read_group(0);
-                read_group(1);
+#pragma unroll
+                for (int g = 0; g < AH; ++g) read_group(g);
 #pragma unroll
                 for (int g = 0; g < 4 * NT; ++g) {
-                    if (g + 2 < 4 * NT) read_group(g + 2);
+                    if (g + AH < 4 * NT) read_group(g + AH);
                     // the correction operands ride behind the last fp16 groups
                     if (g >= 4 * NT - 4) read_b8(g - (4 * NT - 4));
                     if (g == 4 * NT - 2) read_w8(0);
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                     const int j = g / NT, nt = g % NT;
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
-                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % 3], bq[j % 3][pt], acc[pt][nt], 0, 0, 0);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bq[j % (AH + 1)][pt], acc[pt][nt], 0, 0, 0);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
