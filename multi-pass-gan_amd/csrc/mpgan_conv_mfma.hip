@@ -404,8 +404,9 @@ __global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const
 // a_hi*w_lo on the block-scaled fp8 path (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, K = 64
 // per instruction at twice the fp16 rate per K).  The corrections only need ~4 bits: together the
 // three products are accurate to ~2^-15 per operand instead of fp16's 2^-11.
-// One workgroup = WAVES waves = 16 tile rows x 32 pixels; a weight stage is one macro-step of 8 taps
-// (K = 64): [4 fp16 k-steps][w_hi8][w_lo8]; chunks are single channel groups.
+// One workgroup = WAVES waves = 16 tile rows x 32 pixels; a weight stage is one macro-step of 8 tap slots
+// (K = 64): [4 fp16 k-steps][w_hi8][w_lo8].  The slots of a segment form one stream over its channel groups
+// (slot = group * tp + tap), so a stage may end one group and begin the next; every group has its own LDS image.
 // ---------------------------------------------------------------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
 
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
     conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
 }
 
-// F16F8 weight image: per (chunk = channel group, macro-step of 8 taps):
+// F16F8 weight image: per stage (8 consecutive tap slots of the segment's slot stream; fold: 8 channel groups):
 //   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][64 lanes][32 x fp8 hi]  |  [NT][64 lanes][32 x fp8 lo]
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                        int cin, int cout, float wscale, const float* __restrict__ cscale,
