@@ -1159,6 +1159,11 @@ static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec) {
     if (prec == MPG_PREC_F16F8) {
         if (!f8_supported(nt)) return 0;
         const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
+        // a segment whose tables + two images + ring cannot fit the 160 KiB of LDS is "not available at this
+        // precision" (callers then pack for MPG_PREC_F16X3), e.g. 7x7 with four cout tiles
+        const size_t tabs = ss.direct ? TAPOFF_BYTES : 2 * ((((size_t)ss.sc * 8 * 4 + 1023) / 1024) * 1024);
+        if ((tabs < (size_t)TAPOFF_BYTES ? (size_t)TAPOFF_BYTES : tabs) + 2 * (size_t)ss.img_bytes + (size_t)3 * 8 * nt * 1024 > 160 * 1024)
+            return 0;
         return (size_t)ss.sc * 8 * nt * 1024;
     }
     if (prec != MPG_PREC_F16X1 && prec != MPG_PREC_F16X3) return 0;

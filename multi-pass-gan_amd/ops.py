@@ -56,9 +56,13 @@ def flavour_for(prec):
     return G8_F8C if prec == PREC_F16F8 else G8_F16
 
 
-def f8_available(cout):
-    """MPG_PREC_F16F8 is built for every output width of the fused convolution (1..128)"""
-    return 1 <= cout <= 128
+def f8_available(cout, segments=()):
+    """MPG_PREC_F16F8 is built for every output width of the fused convolution (1..128); a segment (kh, kw, cin)
+    whose LDS images do not fit at that width (7x7 with four cout tiles) answers 0 to the pack-size query"""
+    if not 1 <= cout <= 128:
+        return False
+    lib = _lib.load()
+    return all(lib.mpg_conv_pack_size(kh, kw, cin, cout, PREC_F16F8) > 0 for (kh, kw, cin) in segments)
 
 
 def absmax(x):

@@ -329,8 +329,9 @@ class Session(object):
         for pat, pr in self.prec_map:
             if pat in lead:
                 prec = pr
-        if prec == ops.PREC_F16F8 and not ops.f8_available(cout):
-            prec = ops.PREC_F16X3      # F16F8 is built for 1 and 4 cout tiles; other widths keep the fp16 split
+        if prec == ops.PREC_F16F8 and not ops.f8_available(
+                cout, [(sg[3].conv.inputs[1].shape[0], sg[3].conv.inputs[1].shape[1], sg[5]) for sg in segs]):
+            prec = ops.PREC_F16X3      # shapes the F16F8 kernels do not cover keep the fp16 split
 
         emit = {"f32": True, "g8": False, "g8c": False}
 

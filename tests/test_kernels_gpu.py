@@ -108,6 +108,12 @@ F8_CASES = [
     (1, 16, 64, 128, 64, 3, "relu", True),     # 2 cout tiles
     (1, 16, 32, 96, 96, 5, "lrelu", True),     # 3 cout tiles
     (1, 18, 32, 48, 48, 5, None, False),
+    # slot-stream corner cases: 49 taps x 16 groups (largest tap tables), 4 taps (slots padded to 8),
+    # 36 taps over 3 groups, 9 taps padded to 12 with an odd group count
+    (1, 16, 32, 128, 64, 7, "relu", False),
+    (1, 16, 32, 16, 32, 2, None, False),
+    (1, 20, 36, 24, 64, 6, "lrelu", False),
+    (2, 16, 32, 40, 128, 3, "relu", True),
 ]
 
 
@@ -137,6 +143,16 @@ def test_conv2d_fused_f16f8(gpu_ops, case):
         assert err < 0.5 * rel_l2(y1.cpu().numpy(), ref)
     else:
         assert rel_l2(y1.cpu().numpy(), ref) < 1e-5
+
+
+def test_f16f8_unavailable_shapes_say_so(gpu_ops, mpg):
+    """7x7 with four cout tiles does not fit the LDS at MPG_PREC_F16F8: the pack size query answers 0 (callers fall
+    back to MPG_PREC_F16X3), it does not fail at launch"""
+    from mpgan_amd import _lib
+    lib = _lib.load()
+    assert lib.mpg_conv_pack_size(7, 7, 128, 128, 2) == 0
+    assert lib.mpg_conv_pack_size(7, 7, 128, 128, 3) > 0
+    assert lib.mpg_conv_pack_size(7, 7, 128, 64, 2) > 0
 
 
 def test_f16f8_chain_and_flavour_check(gpu_ops, mpg):
