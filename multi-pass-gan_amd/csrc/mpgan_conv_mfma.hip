@@ -228,22 +228,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
                 }
             }
             if (a.y_g8c != nullptr) {
-                // lanes 0-31: hi16 plane; lanes 32-63: the {hi8 | lo8} plane
+                // lane (pixel r, half hh) converts channel group 2 i + hh and writes BOTH of its planes (hi16, then
+                // {hi8 | lo8}): no divergence between the halves, 512-byte runs per plane and half-wave
                 const size_t plane_px = (size_t)a.h * a.w;
                 if (r < npx) {
-                    for (int cg = 0; cg < cg_out; ++cg) {
+                    for (int cg = hh; cg < cg_out; cg += 2) {
                         const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
                         const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
                         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        char* dst = a.y_g8c + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
-                        if (hh) {
-                            *reinterpret_cast<int4*>(dst) = g8c_plane1(v);
-                        } else {
-                            half8 o;
+                        char* dst = a.y_g8c + ((((size_t)n * cg_out + cg) * 2) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                        half8 o;
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
-                            *reinterpret_cast<half8*>(dst) = o;
-                        }
+                        for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
+                        *reinterpret_cast<half8*>(dst) = o;
+                        *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(v);
                     }
                 }
             }
