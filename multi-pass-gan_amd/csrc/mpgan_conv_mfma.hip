@@ -840,7 +840,9 @@ __device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, in
 // cin x COUT FMAs whose weights are wave-uniform scalar loads.
 constexpr int SM_TW = 32, SM_TH = 8;
 
-template <int COUT>
+// COUT / CINB: output channels / input channels per segment rounded up to 1, 2, 4, 8 (compile-time loop bounds: the
+// weight table holds zeros beyond cin and cout, a G8 group holds zeros beyond its channels)
+template <int COUT, int CINB>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
     __shared__ __attribute__((aligned(16))) float tile[(SM_TH + 6) * (SM_TW + 6) * 8];
     __shared__ __attribute__((aligned(16))) float wl[49 * 64];      // the segment's table: LDS broadcasts instead of scalar loads
@@ -879,13 +881,13 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
                 const float4 lo4 = src[0];
                 const float* wt = wl + (ky * g.kw + kx) * 64;
                 float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, 0.f, 0.f, 0.f, 0.f};
-                if (g.cin > 4) {
+                if (CINB > 4) {
                     const float4 hi4 = src[1];
                     v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
                 }
 #pragma unroll
-                for (int ci = 0; ci < 8; ++ci) {
-                    if (ci < g.cin) {
+                for (int ci = 0; ci < CINB; ++ci) {
+                    {
                         float wv[8];
                         if (COUT > 4) {
                             const float4 w0 = *reinterpret_cast<const float4*>(wt + ci * 8);
@@ -1250,10 +1252,20 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
             const size_t total = (size_t)d->n * d->h * d->w;
             (void)total;
             const dim3 sg((unsigned)((d->w + SM_TW - 1) / SM_TW), (unsigned)((d->h + SM_TH - 1) / SM_TH), (unsigned)d->n);
-            if (d->cout == 1) hipLaunchKernelGGL(conv_small_kernel<1>, sg, dim3(256), 0, (hipStream_t)stream, sa);
-            else if (d->cout == 2) hipLaunchKernelGGL(conv_small_kernel<2>, sg, dim3(256), 0, (hipStream_t)stream, sa);
-            else if (d->cout <= 4) hipLaunchKernelGGL(conv_small_kernel<4>, sg, dim3(256), 0, (hipStream_t)stream, sa);
-            else hipLaunchKernelGGL(conv_small_kernel<8>, sg, dim3(256), 0, (hipStream_t)stream, sa);
+            int cmax = 1;
+            for (int s = 0; s < d->nseg; ++s) cmax = d->seg[s].cin > cmax ? d->seg[s].cin : cmax;
+            const int cob = d->cout == 1 ? 1 : d->cout == 2 ? 2 : d->cout <= 4 ? 4 : 8;
+            const int cib = cmax == 1 ? 1 : cmax == 2 ? 2 : cmax <= 4 ? 4 : 8;
+            switch (cob * 16 + cib) {
+#define MPG_SMALL(CO, CI) \
+    case CO * 16 + CI: hipLaunchKernelGGL((conv_small_kernel<CO, CI>), sg, dim3(256), 0, (hipStream_t)stream, sa); break;
+                MPG_SMALL(1, 1) MPG_SMALL(1, 2) MPG_SMALL(1, 4) MPG_SMALL(1, 8)
+                MPG_SMALL(2, 1) MPG_SMALL(2, 2) MPG_SMALL(2, 4) MPG_SMALL(2, 8)
+                MPG_SMALL(4, 1) MPG_SMALL(4, 2) MPG_SMALL(4, 4) MPG_SMALL(4, 8)
+                MPG_SMALL(8, 1) MPG_SMALL(8, 2) MPG_SMALL(8, 4) MPG_SMALL(8, 8)
+#undef MPG_SMALL
+                default: break;
+            }
             MPG_LAUNCH_CHECK("conv_small_kernel");
         }
     }
