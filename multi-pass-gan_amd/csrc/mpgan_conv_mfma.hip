@@ -804,6 +804,7 @@ struct SmallSeg {
 
 struct SmallArgs {
     int n, h, w, cout, nseg, f8c_in;
+    int tile_floats;      // floats of the halo tile of the largest segment; the weight table follows it in LDS
     SmallSeg seg[MPG_MAX_SEG];
     const float* bias;
     const float* in_amax;
@@ -844,8 +845,11 @@ constexpr int SM_TW = 32, SM_TH = 8;
 // weight table holds zeros beyond cin and cout, a G8 group holds zeros beyond its channels)
 template <int COUT, int CINB>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[(SM_TH + 6) * (SM_TW + 6) * 8];
-    __shared__ __attribute__((aligned(16))) float wl[49 * 64];      // the segment's table: LDS broadcasts instead of scalar loads
+    // LDS sized by the launch for the largest segment (5x5: 20 KB, so eight blocks = 32 waves share a CU and the
+    // 2048 tiles of 8 slices of 256^2 are one round): halo tile, then the segment's weight table (LDS broadcasts)
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    float* tile = small_lds;
+    float* wl = small_lds + a.tile_floats;
     const int tid = threadIdx.x;
     const int tx = tid % SM_TW, ty = tid / SM_TW;
     const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
@@ -1252,13 +1256,21 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
             const size_t total = (size_t)d->n * d->h * d->w;
             (void)total;
             const dim3 sg((unsigned)((d->w + SM_TW - 1) / SM_TW), (unsigned)((d->h + SM_TH - 1) / SM_TH), (unsigned)d->n);
-            int cmax = 1;
-            for (int s = 0; s < d->nseg; ++s) cmax = d->seg[s].cin > cmax ? d->seg[s].cin : cmax;
+            int cmax = 1, tmax = 1, tile_px = 0;
+            for (int s = 0; s < d->nseg; ++s) {
+                const mpg_conv_seg& g = d->seg[s];
+                cmax = g.cin > cmax ? g.cin : cmax;
+                tmax = g.kh * g.kw > tmax ? g.kh * g.kw : tmax;
+                const int px = (SM_TH + g.kh - 1) * (SM_TW + g.kw - 1);
+                tile_px = px > tile_px ? px : tile_px;
+            }
+            sa.tile_floats = tile_px * 8;
+            const size_t small_lds = ((size_t)tile_px * 8 + (size_t)tmax * 64) * sizeof(float);
             const int cob = d->cout == 1 ? 1 : d->cout == 2 ? 2 : d->cout <= 4 ? 4 : 8;
             const int cib = cmax == 1 ? 1 : cmax == 2 ? 2 : cmax <= 4 ? 4 : 8;
             switch (cob * 16 + cib) {
 #define MPG_SMALL(CO, CI) \
-    case CO * 16 + CI: hipLaunchKernelGGL((conv_small_kernel<CO, CI>), sg, dim3(256), 0, (hipStream_t)stream, sa); break;
+    case CO * 16 + CI: hipLaunchKernelGGL((conv_small_kernel<CO, CI>), sg, dim3(256), small_lds, (hipStream_t)stream, sa); break;
                 MPG_SMALL(1, 1) MPG_SMALL(1, 2) MPG_SMALL(1, 4) MPG_SMALL(1, 8)
                 MPG_SMALL(2, 1) MPG_SMALL(2, 2) MPG_SMALL(2, 4) MPG_SMALL(2, 8)
                 MPG_SMALL(4, 1) MPG_SMALL(4, 2) MPG_SMALL(4, 4) MPG_SMALL(4, 8)
