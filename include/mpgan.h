@@ -118,7 +118,9 @@ typedef struct mpg_conv_desc {
                                * and activation.  Used for gradients, whose magnitude is below the fp16 normal range. */
 } mpg_conv_desc;
 
-/* bytes of the packed weight image of one segment. */
+/* bytes of the packed weight image of one segment; 0 when the shape is not available at `prec` (kernel larger
+ * than 7x7, cout > 128, or -- MPG_PREC_F16F8 only -- LDS images that do not fit, e.g. 7x7 with cout > 96:
+ * pack such a segment for MPG_PREC_F16X3 instead). */
 size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec);
 
 /* Pack W[kh,kw,w_cin_total,cout] (HWIO fp32, device; GAN.py:93) channels
