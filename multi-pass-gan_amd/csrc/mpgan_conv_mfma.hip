@@ -240,8 +240,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
                         half8 o;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
-                        *reinterpret_cast<half8*>(dst) = o;
-                        *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(v);
+                        __builtin_nontemporal_store(o, reinterpret_cast<half8*>(dst));
+                        typedef int v4i_t __attribute__((ext_vector_type(4)));
+                        const int4 p1 = g8c_plane1(v);
+                        v4i_t p1v = {p1.x, p1.y, p1.z, p1.w};
+                        __builtin_nontemporal_store(p1v, reinterpret_cast<v4i_t*>(dst + plane_px * 16));
                     }
                 }
             }
