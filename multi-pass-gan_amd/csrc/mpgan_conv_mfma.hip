@@ -93,6 +93,13 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+__device__ __forceinline__ void dma16_stream(const char* src, char* lds_wave_base) {
+    // same, with the non-temporal hint: activation tiles are read once or twice and should not push the weights
+    // (re-read by every tile) out of L2
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     // lane l of the wave copies 16 bytes from its own `src` to lds_wave_base + 16*l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 if (pl < 2 && chunk < sg.cg_seg && hy < sg.ih && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w)
                     src = sg.x + ((((size_t)n * sg.cg_total + sg.g_off + chunk) * 2 + pl) * plane_px +
                                   (size_t)(yy >> sg.up) * sg.ws + (xx >> sg.up)) * 16;
-                dma16(src, buf + pc * 1024);
+                dma16_stream(src, buf + pc * 1024);
             }
         };
         auto dma_stage = [&](int stage) {
