@@ -514,7 +514,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                     int g = 2 * j + hh;
                     g = g < grem ? g : grem;                 // groups past the segment: zero weights
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) b_hi[j][pt] = *reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride));
+                    for (int pt = 0; pt < PT; ++pt)
+                        b_hi[j][pt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride)));   // read once
                 }
                 {
 #pragma unroll
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                         g = g < grem ? g : grem;
 #pragma unroll
                         for (int pt = 0; pt < PT; ++pt) {
-                            const int4 v = *reinterpret_cast<const int4*>(xs + (pixo[pt] + g * gstride + plane_bytes));
+                            typedef int v4i_t __attribute__((ext_vector_type(4)));
+                            const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(xs + (pixo[pt] + g * gstride + plane_bytes)));
                             b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
                             b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
                         }
