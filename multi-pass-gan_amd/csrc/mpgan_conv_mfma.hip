@@ -473,7 +473,12 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
     const int sa_hi = (127 - SA_HI) * 0x01010101;
     const int sa_lo = (127 - SA_LO) * 0x01010101;
 
-    for (int s = 0; s < ((a.dbg & 1) ? 0 : a.nseg); ++s) {
+    // The K segments are independent partial sums.  Blocks that share a CU (workgroups go round-robin over the 8
+    // XCDs, then over the 32 CUs of an XCD: co-resident blocks differ in bit 8 of the id) walk them in opposite
+    // orders, so one block's HBM-bound direct 1x1 segment runs under the other's LDS / MFMA-bound 5x5 segment.
+    const int seg_flip = (NT == 1 && a.nseg > 1) ? ((int)(blockIdx.x >> 8) & 1) : 0;
+    for (int s0 = 0; s0 < ((a.dbg & 1) ? 0 : a.nseg); ++s0) {
+        const int s = seg_flip ? a.nseg - 1 - s0 : s0;
         const auto& sg = ap->seg[s];
         if (NT <= 2 && sg.direct) {
             // 1x1 segment over cg_seg >= 2 channel groups: no halo, so no LDS image.  The G8 rows are already
