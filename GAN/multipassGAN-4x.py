@@ -50,7 +50,7 @@ for name, default in [
         ("saveMetaData", 0), ("use_spatialdisc", True), ("clamping", True), ("simLowLength", 64), ("simLowWidth", 64),
         ("simLowHeight", 64), ("overlappedpixel", 3), ("startIndex", 0), ("useAvgDepool", False), ("avgMode", 0),
         ("velScale", 1.0), ("upsamplingMode", 2), ("upsampledData", False), ("sliceMode", 0), ("interpMode", 1),
-        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0)]:
+        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0), ("prec", "2")]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
 
@@ -254,7 +254,7 @@ except FileNotFoundError as e:
     params = None
 gen = multipass.Generator("gen_resnet", dict(tile_low=simSizeLow, up_res=upRes, channels=n_ch,
                                              upsampling_mode=upsampling_mode, batch_norm=batch_norm),
-                          params, device=device, seed=int(P["randSeed"]))
+                          params, prec=ops.parse_prec(P["prec"]), device=device, seed=int(P["randSeed"]))
 print('*****OUTPUT ONLY*****')
 s = simSizeHigh
 for layerno in range(frame_min, frame_max):

@@ -51,6 +51,7 @@ firstNNArch = int(ph.getParam("firstNNArch", True))
 transposeAxis = int(ph.getParam("transposeAxis", 0))
 gpu = ph.getParam("gpu", "0")
 synthWeights = int(ph.getParam("synthWeights", 0))          # extension: seeded random weights if no checkpoint
+prec = ph.getParam("prec", "2")                             # extension: 2 = f16f8 (default), 3 = f16x3 (fp32-grade)
 nets = []
 for k in (1, 2, 3):
     nets.append(dict(
@@ -62,6 +63,8 @@ for k in (1, 2, 3):
         max_fms=int(ph.getParam("maxFms%d" % k, 256)),
         filter_size=int(ph.getParam("filterSize%d" % k, 3))))
 ph.checkUnusedParams()
+from mpgan_amd import ops as _ops  # noqa: E402
+prec = _ops.parse_prec(prec)
 
 if useVorticities or useFlags or useK_Eps_Turb or usePixelShuffle:
     print("ERROR: vorticity / flag / turbulence channels and pixel shuffle are not part of the multi-pass hot path")
@@ -106,7 +109,7 @@ for k, n in enumerate(nets):
             exit(1)
         params = None
         print("Model %d: no checkpoint, seeded synthetic weights (synthWeights 1)" % (k + 1))
-    gens.append(multipass.Generator("growing_gen", cfg, params, device=device, seed=randSeed + k))
+    gens.append(multipass.Generator("growing_gen", cfg, params, prec=prec, device=device, seed=randSeed + k))
 if not gens:
     print("At least one network has to be loaded.")
     exit(1)

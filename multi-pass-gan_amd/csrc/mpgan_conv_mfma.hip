@@ -20,6 +20,8 @@
 // Replaces tf.nn.conv2d + bias + batch_norm + activation (+ residual 1x1 conv, + pixel_norm,
 // + nearest upsample, + channel concat) of tools_wscale/GAN.py:80-119,472-474,501-541 and
 // GAN/multipassGAN-4x.py:505-526, GAN/multipassGAN-out.py:220-237,357 (reference tree).
+#include <mutex>
+
 #include "mpgan_internal.h"
 
 namespace {
@@ -1090,44 +1092,59 @@ SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
 }
 
 template <int NT>
-void launch_f8(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_f8_kernel<NT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_f8(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+    static int lds_limit[64] = {0};
+    if (lds > 48 * 1024) {
+        hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&conv_mfma_f8_kernel<NT>), (int)lds, lds_limit);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((conv_mfma_f8_kernel<NT>), grid, dim3(Pipe8<NT>::WAVES * 64), lds, st, a);
+    return hipSuccess;
 }
 
 template <int NT, int PREC>
-void launch_one(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, PREC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+hipError_t launch_one(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+    static int lds_limit[64] = {0};
+    if (lds > 48 * 1024) {
+        hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<NT, PREC>), (int)lds, lds_limit);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((conv_mfma_kernel<NT, PREC>), grid, dim3(256), lds, st, a);
+    return hipSuccess;
 }
 
 template <int PREC>
-void launch_nt(int nt, dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+hipError_t launch_nt(int nt, dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
     switch (nt) {
-        case 1: launch_one<1, PREC>(grid, lds, st, a); break;
-        case 2: launch_one<2, PREC>(grid, lds, st, a); break;
-        case 3: launch_one<3, PREC>(grid, lds, st, a); break;
-        default: launch_one<4, PREC>(grid, lds, st, a); break;
+        case 1: return launch_one<1, PREC>(grid, lds, st, a);
+        case 2: return launch_one<2, PREC>(grid, lds, st, a);
+        case 3: return launch_one<3, PREC>(grid, lds, st, a);
+        default: return launch_one<4, PREC>(grid, lds, st, a);
     }
 }
 
-// 256 zero bytes per device: the DMA source of out-of-image halo pixels (allocated on first use,
-// outside any stream capture; the launch functions themselves never allocate afterwards)
+// 256 zero bytes per device: the DMA source of out-of-image halo pixels.  Allocated on the first launch on a
+// device under a lock; the fill is a blocking hipMemset followed by a device synchronise, so the page is zero before
+// ANY stream (torch's side streams are non-blocking) can run a kernel that reads it.  Later calls are a lock-free
+// read.  Must first happen outside a stream capture (Session / Trainer run one eager step before capturing).
 const char* zero_buffer() {
+    static std::mutex mu;
     static char* per_dev[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!per_dev[dev]) {
-        char* p = nullptr;
+    char* p = __atomic_load_n(&per_dev[dev], __ATOMIC_ACQUIRE);
+    if (p) return p;
+    std::lock_guard<std::mutex> lock(mu);
+    p = per_dev[dev];
+    if (!p) {
         if (hipMalloc(&p, 256) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-        per_dev[dev] = p;
+        if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        __atomic_store_n(&per_dev[dev], p, __ATOMIC_RELEASE);
     }
-    return per_dev[dev];
+    return p;
 }
 
 }  // namespace
@@ -1372,16 +1389,18 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_fused: LDS budget %zu exceeds 160 KiB", lds);
     const dim3 grid((unsigned)nblk);
+    hipError_t le;
     if (f8) {
         switch (nt) {
-            case 1: launch_f8<1>(grid, lds, (hipStream_t)stream, a); break;
-            case 2: launch_f8<2>(grid, lds, (hipStream_t)stream, a); break;
-            case 3: launch_f8<3>(grid, lds, (hipStream_t)stream, a); break;
-            default: launch_f8<4>(grid, lds, (hipStream_t)stream, a); break;
+            case 1: le = launch_f8<1>(grid, lds, (hipStream_t)stream, a); break;
+            case 2: le = launch_f8<2>(grid, lds, (hipStream_t)stream, a); break;
+            case 3: le = launch_f8<3>(grid, lds, (hipStream_t)stream, a); break;
+            default: le = launch_f8<4>(grid, lds, (hipStream_t)stream, a); break;
         }
     } else if (d->prec == MPG_PREC_F16X3)
-        launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);
+        le = launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);
     else
-        launch_nt<1>(nt, grid, lds, (hipStream_t)stream, a);
+        le = launch_nt<1>(nt, grid, lds, (hipStream_t)stream, a);
+    if (le != hipSuccess) return mpg::hip_check(le, "mpg_conv2d_fused: hipFuncSetAttribute(dynamic LDS)");
     MPG_LAUNCH_CHECK("conv_mfma_kernel");
 }

@@ -51,37 +51,21 @@ __device__ __forceinline__ float pow2_scale(float amax) {
     return ldexpf(1.f, 9 - e);
 }
 
-// channel-chunk plan of one conv segment; shared by the packer and the kernel launch
-struct SegPlan {
-    int kc;       // input channels per LDS chunk (multiple of 8)
-    int g;        // 8-channel groups per chunk
-    int nchunks;  // chunks over cin
-    int sc;       // weight stages per chunk
-    int ps;       // LDS bytes per halo pixel per plane
-};
-
-inline int pick_kc(int cin, int kc_max) {
-    const int cin8 = (cin + 7) & ~7;
-    if (kc_max <= 0) kc_max = 32;
-    if (cin8 <= kc_max) return cin8;
-    const int cand[4] = {32, 24, 16, 8};
-    for (int i = 0; i < 4; ++i)
-        if (cand[i] <= kc_max && cin8 % cand[i] == 0) return cand[i];
-    return 8;
-}
-
-inline SegPlan make_plan(int kh, int kw, int cin, int kc_max, int ks) {
-    SegPlan p;
-    if (kh == 1 && kw == 1) kc_max = 32;   // no halo: a 256-pixel image, the widest chunk always fits
-    p.kc = pick_kc(cin, kc_max);
-    p.g = p.kc / 8;
-    const int cin8 = (cin + 7) & ~7;
-    p.nchunks = (cin8 + p.kc - 1) / p.kc;
-    const int tg = kh * kw * p.g;          // 8-channel groups per chunk over all taps
-    const int ksteps = (tg + 1) / 2;       // one MFMA k-step (K=16) eats two groups
-    p.sc = (ksteps + ks - 1) / ks;
-    p.ps = (p.g & 1) ? 16 * p.g : 16 * (p.g + 1);   // odd number of 16-B slots => conflict-free b128 reads
-    return p;
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): hipFuncSetAttribute is a driver call and the
+// value never has to shrink, so a launch only pays for it the first time a size above the recorded one is asked.
+// `slot` is a per-kernel static array of 64 ints (one per device), zero-initialised.
+inline hipError_t ensure_dyn_lds(const void* kern, int bytes, int* slot) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    int seen = __atomic_load_n(&slot[dev], __ATOMIC_ACQUIRE);
+    if (bytes <= seen) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    while (seen < bytes && !__atomic_compare_exchange_n(&slot[dev], &seen, bytes, false, __ATOMIC_RELEASE, __ATOMIC_ACQUIRE)) {
+    }
+    return hipSuccess;
 }
 
 }  // namespace mpg

@@ -281,12 +281,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 template <int KW, int COTW, int PREC>
 hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes) {
     auto kern = wgrad_mfma_kernel<KW, COTW, PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static int lds_limit[64] = {0};
+    hipError_t e = mpg::ensure_dyn_lds((const void*)kern, 160 * 1024, lds_limit);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }

@@ -9,8 +9,12 @@ per-rank slabs (S^3*4/R bytes each; 67 MB at 512^3, R = 8).
 """
 import os
 
-import torch
-import torch.distributed as dist
+# dmabuf IPC (RCCL and tensor sharing across processes on this driver): read when the HIP runtime starts, so it is
+# exported at import, before anything can have touched the GPU -- launch.rank_env / bench.py set it even earlier
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 class _Gathered(object):
@@ -92,7 +96,6 @@ def init_from_env(backend=None):
         return None, device
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend is None:
         backend = "nccl" if use_gpu else "gloo"
     if not dist.is_initialized():

@@ -44,7 +44,8 @@ class Generator(object):
     """One generator network: private graph + session.  Call with device tensors
     x [N,h,w,C] (and y [N,H,W] for the later 8x generators); returns [N,H,W]."""
 
-    def __init__(self, kind, cfg, params=None, prec=ops.DEFAULT_PREC, device="cuda:0", seed=777, prec_map=None):
+    def __init__(self, kind, cfg, params=None, prec=None, device="cuda:0", seed=777, prec_map=None):
+        prec = ops.INFERENCE_PREC if prec is None else prec
         self.kind, self.cfg = kind, dict(cfg)
         prev = G.get_default_graph()
         self.graph = G.reset_default_graph()

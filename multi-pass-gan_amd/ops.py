@@ -12,7 +12,25 @@ import torch
 from . import _lib
 from ._lib import G8_F16, G8_F8C, PREC_F16F8, PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
 
-DEFAULT_PREC = PREC_F16X3
+DEFAULT_PREC = PREC_F16X3     # kernel-level default (weight packing, generic sessions, training)
+# what the inference drivers and multipass.Generator run unless told otherwise (`prec` parameter): held to
+# 5e-4 relative L2 of the oracle at the full C2 / C4 sizes by tests/test_fullsize_gpu.py (north_star: 1e-3)
+INFERENCE_PREC = PREC_F16F8
+
+
+def parse_prec(v):
+    """`prec` parameter of the GAN/ drivers: 2 / "f16f8" (default), 3 / "f16x3" (fp32-grade), 1 / "f16x1" """
+    names = {"f16f8": PREC_F16F8, "f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "fp32": PREC_F16X3}
+    s = str(v).strip().lower()
+    if s in names:
+        return names[s]
+    try:
+        p = int(s)
+    except ValueError:
+        p = -1
+    if p not in (PREC_F16X1, PREC_F16F8, PREC_F16X3):
+        raise _lib.MpgError("prec %r: expected 1 (f16x1), 2 (f16f8) or 3 (f16x3)" % (v,))
+    return p
 
 
 def _stream():

@@ -111,6 +111,11 @@ class Session(object):
         self._packed = {}
         self._folded = {}
         self._cache_version = -1
+        # measurement hook: when `tap` is a substring of a fused launch's leading weight name, the launch's
+        # operands (G8 segments taken from the running pipeline, bias, epilogue flags) are kept in `tapped`
+        # so that bench.py can re-issue exactly that launch on exactly those activations
+        self.tap = None
+        self.tapped = None
 
     # ------------------------------------------------------------------ public
     def run(self, fetches, feed_dict=None):
@@ -343,6 +348,10 @@ class Session(object):
                 seg_objs.append(ops.Segment(g8, pk, off, up))
             bias = self._bias_for(terms)
             pa = self._f32(env, post_add) if post_add is not None else None
+            if self.tap is not None and self.tap in lead:
+                self.tapped = dict(segments=seg_objs, out_hw=out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn,
+                                   pn_eps=pn_eps, post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"],
+                                   want_g8c=emit["g8c"])
             res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
                                    post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"], want_g8c=emit["g8c"])
             res = list(res) if isinstance(res, tuple) else [res]

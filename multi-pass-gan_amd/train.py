@@ -407,6 +407,9 @@ class TrainSession(object):
     def __init__(self, variables, graph=None, prec=ops.PREC_F16X3, bn_decay=0.999, device="cuda:0"):
         self.graph = graph or G.get_default_graph()
         self.vars = variables
+        if prec not in (ops.PREC_F16X3, ops.PREC_F16X1):
+            # the weight-gradient kernel contracts over pixels with fp16 hi/lo operands only
+            raise _lib.MpgError("training runs MPG_PREC_F16X3 (or F16X1); MPG_PREC_F16F8 is an inference mode")
         self.prec = prec
         self.bn_decay = bn_decay
         self.device = torch.device(device)

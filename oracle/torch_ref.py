@@ -59,3 +59,29 @@ def gen_resnet(params, x_nhwc, up_res=4, upsampling_mode=2, batch_norm=True):
             _, s = conv_layer(params, "generator/g_s%d" % i, x, s2, 1, None, 1, bn)
             x = torch.relu(b + s)
         return x.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+class fast_convs(object):
+    """Context manager: ``oracle.ops.conv2d_same`` (float64 numpy, tap by tap) is replaced by the
+    PyTorch-CPU fp32 convolution above while the block runs, so that the numpy restatements of the
+    8x generators (``oracle.nets.growing_gen``) finish in seconds at 512^2 -- the full-size parity tests
+    need that.  Everything else (resize, pixel_norm, residual sums) stays the numpy code.  Cross-checked
+    against the float64 convolution in tests/test_oracle.py."""
+
+    def __enter__(self):
+        from . import ops
+        self._ops, self._saved = ops, ops.conv2d_same
+
+        def conv(x, w, stride=(1, 1)):
+            assert stride[0] == stride[1]
+            with torch.no_grad():
+                xt = torch.as_tensor(np.ascontiguousarray(np.transpose(np.asarray(x, dtype=np.float32), (0, 3, 1, 2))))
+                y = conv2d_same(xt, np.asarray(w, dtype=np.float32), stride[0])
+                return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
+
+        ops.conv2d_same = conv
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.conv2d_same = self._saved
+        return False

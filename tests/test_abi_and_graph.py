@@ -104,14 +104,14 @@ def test_gan_layer_side_effects(mpg):
 
 def test_fusion_plan(mpg):
     from mpgan_amd import multipass as MP
-    g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)
+    g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None, prec=3)
     launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] == "conv2d_fused"]
     assert [e["cout"] for e in launches] == [2, 8, 128, 128, 32, 8, 2, 1]
     # activations between fused launches travel as G8 only; the fetched tensor is fp32
     assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True, "g8c": False}] * 7
     assert launches[-1]["emit"] == {"f32": True, "g8": False, "g8c": False}
     # F16F8: every launch of this net has 1 or 4 cout tiles, so all of it runs in that mode
-    gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None, prec=2)
+    gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)   # default: F16F8
     lf = [e for e in gf.sess.plan_summary(gf.sampler) if e["kind"] == "conv2d_fused"]
     assert all(e["prec"] == 2 for e in lf) and all(e["emit"]["g8c"] and not e["emit"]["g8"] for e in lf[:-1])
     # a per-launch precision map mixes modes; a tensor feeding both kinds of launch is emitted in both G8 flavours

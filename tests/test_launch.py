@@ -1,0 +1,57 @@
+"""The self-launch path of `bench.py --gpus N` (multi-pass-gan_amd/launch.py), rehearsed on CPU:
+N fresh children with the torch.distributed.run environment, rank 0's JSON line relayed, worst
+return code propagated.  The parent must never initialise the GPU runtime."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ECHO = os.path.join(ROOT, "tests", "_rank_echo.py")
+
+
+@pytest.mark.timeout(300)
+def test_spawn_ranks_relays_rank0_json(mpg):
+    from mpgan_amd import launch
+    rc, out = launch.spawn_ranks(ECHO, [], 2, timeout=240)
+    assert rc == 0, out
+    line = launch.last_json_line(out)
+    assert json.loads(line) == {"n_gpus": 2, "sum": 3.0}
+    assert "rank 1" not in out            # only rank 0's stdout is relayed
+
+
+@pytest.mark.timeout(300)
+def test_spawn_ranks_propagates_failure(mpg):
+    from mpgan_amd import launch
+    rc, out = launch.spawn_ranks(ECHO, ["1"], 2, timeout=240)
+    assert rc == 3
+
+
+def test_rank_env_and_json_picker(mpg):
+    from mpgan_amd import launch
+    env = launch.rank_env(1, 4, 1234, base={})
+    assert env["RANK"] == "1" and env["LOCAL_RANK"] == "1" and env["WORLD_SIZE"] == "4"
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "1234"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert launch.last_json_line("warning\n{\"a\": 1}\ntrailing text\n") == "{\"a\": 1}"
+    assert launch.last_json_line("no json here") is None
+
+
+@pytest.mark.timeout(600)
+def test_bench_parent_launches_children_without_touching_the_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns two ranks.  Without a GPU the ranks stop
+    with "needs an MI355X"; the parent reports their failure (rc != 0, no JSON line) and does not hang.
+    The parent path does not even import torch (checked below), so it cannot have initialised the runtime."""
+    chk = ("import sys; sys.path.insert(0, %r); import bench, mpgan_amd.launch; "
+           "assert 'torch' not in sys.modules, 'parent path imports torch'" % ROOT)
+    subprocess.run([sys.executable, "-c", chk], check=True, timeout=120)
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode != 0
+    assert p.stderr.count("needs an MI355X") == 2, p.stderr[-2000:]
+    assert "{" not in p.stdout
