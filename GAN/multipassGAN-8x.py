@@ -169,7 +169,7 @@ test_path, _ = ph.getNextTestPath(int(P["testPathStartNo"]), basePath)
 print("\nUsing parameters:\n" + ph.paramsToString())
 ph.writeParams(test_path + "params.json")
 
-from mpgan_amd.nets8x import Cfg8x  # noqa: E402
+from mpgan_amd.arch import Cfg8x  # noqa: E402
 from mpgan_amd.train import Trainer8x  # noqa: E402
 
 cfg = Cfg8x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_inputChannels, upsampling_mode=upsampling_mode,

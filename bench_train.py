@@ -183,7 +183,7 @@ def timed(step, batch, args, comm, dev):
 
 
 def bench_c5(args, comm, dev, rank, world, rng):
-    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.arch import Cfg8x
     from mpgan_amd.train import Trainer8x
     cfg = Cfg8x(tileSizeLow=args.tile, upRes=8, n_inputChannels=6, start_fms=256, max_fms=256)
     tr = Trainer8x(cfg, device=str(dev), comm=comm)

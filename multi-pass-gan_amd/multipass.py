@@ -15,7 +15,7 @@ The ``backend`` argument is the operator module (default: the HIP ``ops``).
 import torch
 
 from . import graph as G
-from . import nets, ops
+from . import arch, ops
 from .session import Session, VariableStore
 
 CUTOFF = 0.0005     # multipassGAN-4x.py:1156, multipassGAN-out.py:614
@@ -58,7 +58,7 @@ class Generator(object):
                 mode = c.get("upsampling_mode", 2)
                 side = low if mode == 2 else self.high
                 self.x = G.placeholder([None, side * side * nch], name="x")
-                self.sampler = nets.gen_resnet(self.x, low, up, nch, mode, use_batch_norm=c.get("batch_norm", True))
+                self.sampler = arch.gen_resnet(self.x, low, up, nch, mode, use_batch_norm=c.get("batch_norm", True))
             elif kind == "growing_gen":
                 first = c.get("first_gen", True)
                 n_in = nch + (2 if c.get("add_adj", False) else 0)
@@ -66,14 +66,13 @@ class Generator(object):
                 src = self.x
                 if not first:
                     self.y = G.placeholder([None, None], name="y")
-                    src = nets.second_gen_input(self.x, self.y, low, self.high, nch)
-                self.sampler = nets.growing_gen(
-                    src, low, up, nch, use_batch_norm=c.get("batch_norm", False), currentUpres=nets.log2_int(up),
-                    output=True, firstGen=first, filterSize=c["filter_size"], startFms=c["start_fms"],
-                    maxFms=c["max_fms"], add_adj_idcs=c.get("add_adj", False) if first else False,
-                    first_nn_arch=c.get("first_nn_arch", False), use_res_net=c.get("use_res_net", True),
-                    pixel_norm=c.get("pixel_norm", True), upsampleMode=c.get("upsample_mode", 1),
-                    addBicubicUpsample=c.get("add_bicubic", True))
+                    src = arch.second_gen_input(self.x, self.y, low, self.high, nch)
+                acfg = arch.Cfg8x(tileSizeLow=low, upRes=up, n_inputChannels=n_in if first else nch,
+                                  upsampling_mode=2 if first else 1, upsampleMode=c.get("upsample_mode", 1),
+                                  filterSize=c["filter_size"], start_fms=c["start_fms"], max_fms=c["max_fms"],
+                                  first_nn_arch=c.get("first_nn_arch", False), use_res_net=c.get("use_res_net", True),
+                                  pixel_norm=c.get("pixel_norm", True), addBicubicUpsample=c.get("add_bicubic", True))
+                self.sampler = arch.growing_gen(src, acfg, use_batch_norm=c.get("batch_norm", False), output=True)
             else:
                 raise ValueError("unknown generator kind %r" % (kind,))
         finally:

@@ -660,7 +660,7 @@ class Trainer4x(object):
                  learning_rate=2e-4, beta1=0.5, lambda_l1=1.0, lambda2=0.0, lambda2_l=(1.0, 1.0, 1.0, 1.0),
                  weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777, comm=None,
                  use_tempo=False, lambda_t=1.0, adv_flag=True, clamping=True):
-        from . import nets
+        from . import arch
         from .session import VariableStore
         self.tileSizeLow, self.upRes, self.C = tileSizeLow, upRes, n_inputChannels
         self.tileSizeHigh = tileSizeLow * upRes
@@ -674,24 +674,24 @@ class Trainer4x(object):
         self.x = G.placeholder([None, self.n_input], name="x")
         self.x_disc = G.placeholder([None, self.n_input], name="x_disc")
         self.y = G.placeholder([None, self.n_output], name="y")
-        self.gen_part = nets.gen_resnet(self.x, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
+        self.gen_part = arch.gen_resnet(self.x, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
                                         use_batch_norm=batch_norm, train=True)
         dkw = dict(tileSizeLow=tileSizeLow, upRes=upRes, n_input=self.n_input, n_inputChannels=n_inputChannels,
                    upsampling_mode=upsampling_mode, use_batch_norm=batch_norm, train=True, bn_decay=bn_decay)
-        self.disc = nets.disc_binclass(self.x_disc, self.y, **dkw)
-        self.gen = nets.disc_binclass(self.x_disc, self.gen_part, reuse=True, **dkw)
+        self.disc = arch.disc_binclass(self.x_disc, self.y, **dkw)
+        self.gen = arch.disc_binclass(self.x_disc, self.gen_part, reuse=True, **dkw)
         # temporal discriminator (multipassGAN-4x.py:790-885): three advected frames as channels
         self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
         if use_tempo:
             self.x_t = G.placeholder([None, self.n_input], name="x_t")
-            self.gen_part_t = nets.gen_resnet(self.x_t, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
+            self.gen_part_t = arch.gen_resnet(self.x_t, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
                                               reuse=True, use_batch_norm=batch_norm, train=True)
             self.t_fake = G.placeholder([None, self.n_output * self.n_t], name="t_fake")
             self.t_real = G.placeholder([None, self.n_output * self.n_t], name="t_real")
             tk = dict(tileSizeLow=tileSizeLow, upRes=upRes, n_t_channels=self.n_t, use_batch_norm=batch_norm, train=True,
                       bn_decay=bn_decay)
-            self.gen_t = nets.disc_binclass_cond_tempo(self.t_fake, reuse=False, **tk)
-            self.disc_t = nets.disc_binclass_cond_tempo(self.t_real, reuse=True, **tk)
+            self.gen_t = arch.disc_binclass_cond_tempo(self.t_fake, reuse=False, **tk)
+            self.disc_t = arch.disc_binclass_cond_tempo(self.t_real, reuse=True, **tk)
         self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, bn_decay=bn_decay,
                                  device=device)
         self.g_var = self.sess.trainable("g_")
@@ -840,7 +840,7 @@ class Trainer8x(object):
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
                  prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999, use_tempo=False, lambda_t=1.0,
                  adv_flag=True, clamping=True):
-        from . import nets8x
+        from . import arch
         from .session import VariableStore
         self.cfg = cfg
         self.k, self.k2, self.weight_dld = lambda_l1, lambda2, weight_dld
@@ -860,12 +860,12 @@ class Trainer8x(object):
             x_in = self.x
         else:       # later networks: `y` carries (target, previous pass) as two channels (:1041-1060)
             self.y2 = G.placeholder([None, cfg.n_output * 2], name="y")
-            x_in, self.y_in = nets8x.later_network_input(self.x, self.y2, cfg)
-        self.gen_y = nets8x.growing_gen(x_in, self.percentage, cfg, train=True, currentUpres=self.currentUpres)
+            x_in, self.y_in = arch.later_network_input(self.x, self.y2, cfg)
+        self.gen_y = arch.growing_gen(x_in, cfg, self.percentage, train=True, currentUpres=self.currentUpres)
         dk = dict(cfg=cfg, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
-        self.disc, self.f_y = nets8x.growing_disc(self.y_in, self.x_disc, self.percentage, reuse=False, **dk)
-        self.gen, self.f_g = nets8x.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
-        self.d_out, _ = nets8x.growing_disc(self.y_gp, self.x_disc, self.percentage, reuse=True, **dk)
+        self.disc, self.f_y = arch.growing_disc(self.y_in, self.x_disc, self.percentage, reuse=False, **dk)
+        self.gen, self.f_g = arch.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
+        self.d_out, _ = arch.growing_disc(self.y_gp, self.x_disc, self.percentage, reuse=True, **dk)
         self.k2_ls = list(k2_ls) if k2_ls is not None else [1.0] * len(self.f_y)
         # temporal discriminator (multipassGAN-8x.py:1158-1300; final growing stage, tensorResample advection)
         self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
@@ -875,16 +875,16 @@ class Trainer8x(object):
                 self.y_t2, x_t_in = None, self.x_t
             else:   # (:1171-1172) previous pass of the three frames = channel 1 of y_t
                 self.y_t2 = G.placeholder([None, cfg.n_output * 2], name="yt")
-                x_t_in, _ = nets8x.later_network_input(self.x_t, self.y_t2, cfg)
-            self.gen_ts = nets8x.growing_gen(x_t_in, self.percentage, cfg, reuse=True, train=True,
+                x_t_in, _ = arch.later_network_input(self.x_t, self.y_t2, cfg)
+            self.gen_ts = arch.growing_gen(x_t_in, cfg, self.percentage, reuse=True, train=True,
                                              currentUpres=self.currentUpres)
             tk = dict(cfg=cfg, n_t_channels=self.n_t, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
             self.t_fake = G.placeholder([None, cfg.n_output * self.n_t], name="t_fake")
             self.t_real = G.placeholder([None, cfg.n_output * self.n_t], name="t_real")
             self.t_gp = G.placeholder([None, cfg.n_output * self.n_t], name="t_gp")
-            self.gen_s = nets8x.growing_disc_tempo(self.t_fake, self.percentage, reuse=False, **tk)
-            self.disc_s = nets8x.growing_disc_tempo(self.t_real, self.percentage, reuse=True, **tk)
-            self.t_out = nets8x.growing_disc_tempo(self.t_gp, self.percentage, reuse=True, **tk)
+            self.gen_s = arch.growing_disc_tempo(self.t_fake, self.percentage, reuse=False, **tk)
+            self.disc_s = arch.growing_disc_tempo(self.t_real, self.percentage, reuse=True, **tk)
+            self.t_out = arch.growing_disc_tempo(self.t_gp, self.percentage, reuse=True, **tk)
         self.sess = TrainSession(variables or VariableStore(device, seed=seed), graph=g, prec=prec, device=device)
         if use_wgan_gp:
             self.sess.higher_order_scopes = ("spatial-disc", "tempo-disc")

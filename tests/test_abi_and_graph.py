@@ -147,3 +147,28 @@ def test_trainer_builds_on_cpu_and_refuses_to_run_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.MpgError):
             tr.losses(np.zeros((2, 8 * 8 * 4), np.float32), np.zeros((2, 32 * 32), np.float32))
+
+
+def test_architecture_tables(mpg):
+    """multi-pass-gan_amd/arch.py holds the networks as tables; the widths are those of SURVEY.md appendix A
+    (example_run_output.py:18-47 for the three 8x generators, multipassGAN-8x.py:752-846 for the critics)"""
+    from mpgan_amd import arch
+    assert [u for u, _ in arch.gen_resnet_table(4)] == [("res", "0", 8, 32), ("res", "1", 128, 128), ("res", "2", 32, 8),
+                                                       ("res", "3", 2, 1)]
+    assert [bn for _, bn in arch.gen_resnet_table(1)] == [True, True, True, False]
+    stem, blocks = arch.growing_gen_table(256, 256, 3, True, True)           # net 1
+    assert stem == () and [(up, len(us)) for up, us in blocks] == [(2, 5), (4, 3), (8, 2)]
+    assert blocks[0][1][0] == ("res", "_first", 128, 128) and blocks[1][1][0] == ("res", "_first", 128, 64)
+    assert blocks[2][1] == (("res", "_first", 64, 32), ("res", "_second", 32, 32))
+    stem, blocks = arch.growing_gen_table(192, 192, 3, False, True)          # net 2
+    assert stem == (("res", "_1", 16, 12), ("res", "_2", 24, 48))
+    assert [us for _, us in blocks] == [(("res", "_first", 96, 96), ("res", "_second", 48, 48)),
+                                        (("res", "_first", 48, 48), ("res", "_second", 24, 24)),
+                                        (("res", "_first", 24, 24), ("res", "_second", 12, 12))]
+    stem, blocks = arch.growing_gen_table(192, 96, 3, False, False)          # net 3
+    assert stem == (("pair", "1", 32, 96),)
+    assert [us for _, us in blocks] == [(("pair", "2", 96, 96),), (("pair", "4", 48, 48),), (("pair", "8", 24, 24),)]
+    first, rows = arch.growing_disc_table(256, 256, 8, 3, True, 3)           # net-1 critic: 2->32 | 32->64->64 | 64->128->128 | 128->384->128
+    assert first == 32 and rows == ((8, (4, 4), 32, 64, 64), (4, (4, 4), 64, 128, 128), (2, (4, 4), 128, 384, 128))
+    first, rows = arch.growing_disc_table(192, 192, 8, 3, False, 5)
+    assert first == 24 and [r[1:] for r in rows] == [((5, 5), 24, 24, 48), ((5, 5), 48, 48, 96), ((5, 5), 96, 96, 96)]

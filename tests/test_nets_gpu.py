@@ -142,7 +142,7 @@ def test_disc_binclass_forward(mpg, nch):
     """4x spatial discriminator forward (multipassGAN-4x.py:572-620): strided 4x4 convs, batch norm
     (inference), lrelu, flatten + FC, through the same builder / session as the generators."""
     from mpgan_amd import graph as G
-    from mpgan_amd import nets
+    from mpgan_amd import arch as nets
     from mpgan_amd.session import Session, VariableStore
     low, up = 4, 4
     rng = np.random.default_rng(9)
@@ -176,7 +176,7 @@ def test_growing_disc_forward_inference_session(percentage):
     float64 restatement"""
     import torch
     from mpgan_amd import graph as G
-    from mpgan_amd import nets8x
+    from mpgan_amd import arch as nets8x
     from mpgan_amd.session import Session, VariableStore
     from oracle import train_ref as TR
     from oracle import train_ref8x as TR8

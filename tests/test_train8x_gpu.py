@@ -22,7 +22,7 @@ def rel(a, b):
 
 
 def make(tile=8, C=6, batch=3, fms=32, seed=9, **kw):
-    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.arch import Cfg8x
     from mpgan_amd.train import Trainer8x
     cfg = Cfg8x(tileSizeLow=tile, upRes=8, n_inputChannels=C, start_fms=fms, max_fms=fms)
     tr = Trainer8x(cfg, device=DEV, seed=seed, **kw)
@@ -150,7 +150,7 @@ def test_temporal_critic_losses_and_gradients():
 def test_second_network_training_step():
     """upsampling_mode 1 (the second / third network): two-channel `y` (target, previous pass), residual blocks
     at full resolution, critic without pooling; losses and all gradients vs the restatement"""
-    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.arch import Cfg8x
     from mpgan_amd.train import Trainer8x
     tile, C, batch = 4, 4, 2
     cfg = Cfg8x(tileSizeLow=tile, upRes=8, n_inputChannels=C, upsampling_mode=1, first_nn_arch=False, filterSize=5,
@@ -203,7 +203,7 @@ def test_second_network_temporal_branch():
     import io
     import random
     from mpgan_amd import tilecreator_t as tc
-    from mpgan_amd.nets8x import Cfg8x
+    from mpgan_amd.arch import Cfg8x
     from mpgan_amd.train import Trainer8x
     tile, C = 4, 4
     rng = np.random.default_rng(43)

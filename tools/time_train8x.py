@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, ".")
-from mpgan_amd.nets8x import Cfg8x  # noqa: E402
+from mpgan_amd.arch import Cfg8x  # noqa: E402
 from mpgan_amd.train import Trainer8x  # noqa: E402
 
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 16
