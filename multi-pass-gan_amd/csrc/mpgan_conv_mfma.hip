@@ -419,6 +419,18 @@ __global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const
 // (slot = group * tp + tap), so a stage may end one group and begin the next; every group has its own LDS image.
 // ---------------------------------------------------------------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
+// LDS reads in the K loops use clang vector types only: a read through HIP's struct `int4` makes the compiler put an
+// `s_waitcnt vmcnt(0)` in front of it while LDS-DMA pieces are in flight (it cannot tell the read from the DMA's
+// destination), which serialises every stage behind its own weight / image DMAs; ext_vector_type reads do not.
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// 32 bytes of LDS as two 16-byte reads: a single v8i (32-byte) read is split by the compiler into two ds_read_b128
+// that again carry the conservative `s_waitcnt vmcnt(0)` against pending LDS-DMA
+__device__ __forceinline__ v8i lds_read32(const char* p) {
+    const v4i lo = *reinterpret_cast<const v4i*>(p);
+    const v4i hi = *reinterpret_cast<const v4i*>(p + 16);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 template <int NT>
 struct Pipe8 {
@@ -552,8 +564,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const v8i w8_hi = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
-                    const v8i w8_lo = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+                    const v8i w8_hi = lds_read32(wb + WF16 + (nt * 64 + lane) * 32);
+                    const v8i w8_lo = lds_read32(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
                         acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
@@ -576,6 +588,11 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
         const int NS = sg.sc;
         const int plane_b = sg.np * 16;
         const int ppg = sg.np >> 6;
+        // the E8M0 scale words of the weight planes live in VGPRs across the K loop: as scalars they are spilled and
+        // re-loaded from the kernarg segment every stage, and the `s_waitcnt lgkmcnt(0)` of that scalar load drains
+        // the whole LDS read pipeline in the middle of the stage
+        int sw_hi_v = sg.sw_hi, sw_lo_v = sg.sw_lo;
+        asm volatile("" : "+v"(sw_hi_v), "+v"(sw_lo_v));
 
         for (int q = tid; q < NS * 8; q += THREADS) {
             const int g = q / sg.tp;
@@ -631,8 +648,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             wait_dma_and_barrier<(D - 1) * NI>();
             // tap offsets of the whole stage in two 16-byte reads, before this stage's DMAs are issued (the compiler
             // orders LDS reads behind pending LDS-DMA writes)
-            const int4 o16 = *reinterpret_cast<const int4*>(tap16 + (st * 2 + hh) * 4);
-            const int4 o8 = *reinterpret_cast<const int4*>(tapoff + st * 8 + 4 * hh);
+            const v4i o16 = *reinterpret_cast<const v4i*>(tap16 + (st * 2 + hh) * 4);
+            const v4i o8 = *reinterpret_cast<const v4i*>(tapoff + st * 8 + 4 * hh);
             asm volatile("" ::"v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w), "v"(o8.x), "v"(o8.y), "v"(o8.z), "v"(o8.w));
             // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
             // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
@@ -660,13 +677,13 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                     aq[g % (AH + 1)] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
                 };
                 auto read_w8 = [&](int nt) {
-                    wq[nt & 1][0] = *reinterpret_cast<const v8i*>(wb + WF16 + (nt * 64 + lane) * 32);
-                    wq[nt & 1][1] = *reinterpret_cast<const v8i*>(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+                    wq[nt & 1][0] = lds_read32(wb + WF16 + (nt * 64 + lane) * 32);
+                    wq[nt & 1][1] = lds_read32(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
                 };
                 auto read_b8 = [&](int i) {
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
-                        const int4 v = *reinterpret_cast<const int4*>(img + plane_b + pixb[pt] + to8[i]);
+                        const v4i v = *reinterpret_cast<const v4i*>(img + plane_b + pixb[pt] + to8[i]);
                         b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
                         b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
                     }
@@ -690,9 +707,9 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
                         acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][0], b8_lo[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sg.sw_hi, 0, sa_lo);
+                                                                                   sw_hi_v, 0, sa_lo);
                         acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][1], b8_hi[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sg.sw_lo, 0, sa_hi);
+                                                                                   sw_lo_v, 0, sa_hi);
                     }
                     if (nt + 2 < NT) read_w8(nt + 2);
                 }
