@@ -8,6 +8,7 @@ reference (example_run_output.py:4-8):
 
   upsamplingMode 2, upsampledData 0 : zoom z, slices along z  -> density_low_2x2_%04d.uni
   upsamplingMode 1, upsampledData 1 : slices along x          -> density_low_1x1_%04d.uni
+  upsamplingMode 3, upsampledData 1 : slices along y          -> density_low_0x0_%04d.uni   (third network, :1121-1124)
 
 Training mode (``out 0``) trains the first network (upsamplingMode 2, upsampledData 0) or the second one
 (upsamplingMode 1, upsampledData 1: slices of the zoomed volumes with the first network's output as density) the way
@@ -223,8 +224,9 @@ if not outputOnly:
     device = "cuda:0"
     train_main()
     exit(0)
-if upsampling_mode not in (1, 2) or int(P["dataDim"]) != 2 or int(P["useAvgDepool"]):
-    print("ERROR: only upsamplingMode 2 (first network) and 1 (second network) of the 2D slice path are implemented")
+if upsampling_mode not in (1, 2, 3) or int(P["dataDim"]) != 2 or int(P["useAvgDepool"]):
+    print("ERROR: upsamplingMode 2 (first network), 1 (second) and 3 (third network) of the 2D slice path are implemented; "
+          "mode 0 (linear interpolation between the networks) is used by no example run")
     exit(1)
 simSizeHigh = simSizeLow * upRes
 n_ch = 4 if useVelocities else 1
@@ -238,8 +240,10 @@ floader = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, base_path_y
 x, _, _ = floader.get()
 x_2 = None
 if upsampled_data:
+    # the previous network's volumes (4x.py:180-185)
     fl2 = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, numpy_seed=int(P["randSeed"]),
-                              filename="density_low_2x2_%04d.uni", filename_index_min=frame_min, oldNamingScheme=False,
+                              filename="density_low_1x1_%04d.uni" if upsampling_mode == 3 else "density_low_2x2_%04d.uni",
+                              filename_index_min=frame_min, oldNamingScheme=False,
                               filename_index_max=frame_max, indices=[fromSim], data_fraction=1.0, multi_file_list=["density"])
     x_2, _, _ = fl2.get()
 
@@ -269,18 +273,11 @@ for layerno in range(frame_min, frame_max):
         vol = ops.cutoff(out, multipass.CUTOFF) if generateUni else out
         name = 'density_low_2x2_%04d.uni'
     else:
+        # upsamplingMode 1: planes (z,y) along x -> density_low_1x1; upsamplingMode 3: planes (z,x) along y -> density_low_0x0
         v1 = torch.as_tensor(np.ascontiguousarray(x_2[i][..., 0])).to(device)
-        if n_ch > 1:
-            vel = (low[..., 1:4] * float(upRes)).contiguous()                # 4x.py:278
-            vel[..., 1:3] *= velScale                                        # 4x.py:283 (vy, vz of the 3-channel array)
-            for ax in range(3):
-                vel = ops.axis_zoom_linear(vel, ax, upRes)                   # 4x.py:1095
-            xin = ops.volume_transpose(torch.cat([v1.reshape(s, s, s, 1), vel], dim=3), (2, 0, 1), chan_map=[0, 2, 3, 1])
-        else:
-            xin = ops.volume_transpose(v1, (2, 0, 1)).reshape(s, s, s, 1)
-        out = multipass._run_pass(gen, xin, None, 0, s, 8)
-        vol = ops.volume_transpose(out, (1, 2, 0), cutoff=multipass.CUTOFF if generateUni else 0.0)
-        name = 'density_low_1x1_%04d.uni'
+        vol = multipass.refine_pass_4x(gen, low, v1, upRes, mode=upsampling_mode, batch=8, vel_scale=velScale,
+                                       apply_cutoff=bool(generateUni))
+        name = 'density_low_1x1_%04d.uni' if upsampling_mode == 1 else 'density_low_0x0_%04d.uni'
     torch.cuda.synchronize()
     print(time.time() - start)
     if generateUni:

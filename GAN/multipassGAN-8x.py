@@ -13,8 +13,9 @@ stage completes), the iteration :1990-2060 (spatial critic, temporal critic on a
 through ``train.Trainer8x``, the polynomial learning-rate decay :995-1009 after 6 * stageIter iterations,
 checkpoints ``model_%04d.ckpt.npz`` and the moving-average weights ``model_ema_%04d.ckpt.npz`` :1804-1812.
 
-Not rebuilt: output mode (use multipassGAN-out.py), upsamplingMode 0 (the linear-interpolation variant no example
-run uses), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
+``out 1`` is the per-network output mode (see output_main).
+
+Not rebuilt: upsamplingMode 0 (the linear-interpolation variant no example run uses), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
 scaling (lossScaling is accepted and ignored: the arithmetic is fp32-grade), PNG test images, TensorBoard.
 """
 import math
@@ -56,7 +57,7 @@ for name, default in [
         ("startingIter", 0), ("loadEmas", False), ("useVelInTDisc", False), ("upsampleMode", 1), ("lossScaling", False),
         ("stageIter", 25000), ("decayIter", 25000), ("maxFms", 256), ("use_wgan_gp", False), ("use_res_net", False),
         ("use_mb_stddev", False), ("use_LSGAN", False), ("startFms", 512), ("filterSize", 3), ("outNNTestNo", 17),
-        ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2)]:
+        ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2), ("synthWeights", 0), ("prec", "2")]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
 
@@ -66,8 +67,84 @@ def fail(msg):
     exit(1)
 
 
+def output_main():
+    """``out 1`` (generate3DUniForNewNetwork :1600-1780, output loop :2316-2324): ONE network per invocation, the
+    volumes travel through .uni files as in the commented alternative of example_run_output.py:64-70:
+      upsamplingMode 2, upsampledData 0 : first network          -> density_low_t%04d_2x2_%04d.uni   (t = load_model_test)
+      upsamplingMode 1, upsampledData 1 : density_low_t<outNNTestNo>_2x2 in -> density_low_t%04d_1x1_%04d.uni
+      upsamplingMode 3, upsampledData 1 : density_low_t<outNNTestNo>_1x1 in -> density_low_0x0_%04d.uni
+    with the slicing axis given by transposeAxis (0..3) and the <5e-4 cutoff on every written volume."""
+    from mpgan_amd import multipass, ops, uniio
+    mode, upsampled = int(P["upsamplingMode"]), int(P["upsampledData"])
+    if (mode, upsampled) not in ((2, 0), (1, 1), (3, 1)) or int(P["dataDim"]) != 2 or not int(P["upsampleFirst"]):
+        fail("output mode: upsamplingMode 2 (upsampledData 0) or 1 / 3 (upsampledData 1), dataDim 2, upsampleFirst 1")
+    if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["usePixelShuffle"]):
+        fail("vorticity / flag / k-eps inputs and pixel shuffle are not supported")
+    ta = int(P["transposeAxis"])
+    if ta not in (0, 1, 2, 3):
+        fail("transposeAxis %d (0..3)" % ta)
+    up, sim = int(P["upRes"]), int(P["simSize"])
+    s = sim * up
+    base, sims = P["basePath"], P["packedSimPath"]
+    from_sim, f0, f1 = int(P["fromSim"]), int(P["frame_min"]), int(P["frame_max"])
+    vel = int(P["useVelocities"]) > 0
+    n_ch = 4 if vel else 1
+    first = mode == 2
+    test_no, model_no = int(P["load_model_test"]), int(P["load_model_no"])
+    mfl = ["density"] + (["velocity"] if vel else [])
+    fl = FDL.FluidDataLoader(print_info=3, base_path=sims, base_path_y=sims, numpy_seed=int(P["randSeed"]),
+                             filename="density_low_%04d.uni", filename_index_min=f0, oldNamingScheme=False, filename_y=None,
+                             filename_index_max=f1, indices=[from_sim], data_fraction=1.0, multi_file_list=mfl,
+                             multi_file_list_y=["density"])
+    x_3d, _, _ = fl.get()
+    x_3d[:, :, :, :, 1:4] = float(P["velScale"]) * x_3d[:, :, :, :, 1:4]                     # :361
+    x_2 = None
+    if upsampled:
+        prev_name = ("density_low_t%04d_2x2" if mode == 1 else "density_low_t%04d_1x1") % int(P["outNNTestNo"]) + "_%04d.uni"
+        fl2 = FDL.FluidDataLoader(print_info=0, base_path=sims, numpy_seed=int(P["randSeed"]), filename=prev_name,
+                                  filename_index_min=f0, oldNamingScheme=False, filename_index_max=f1, indices=[from_sim],
+                                  data_fraction=1.0, multi_file_list=["density"])
+        x_2, _, _ = fl2.get()
+    cfg = dict(tile_low=sim, up_res=up, channels=n_ch, first_gen=first, filter_size=int(P["filterSize"]),
+               start_fms=int(P["startFms"]), max_fms=int(P["maxFms"]), add_adj=int(P["add_adj_idcs"]) > 0 and first,
+               first_nn_arch=int(P["firstNNArch"]) > 0 and first, use_res_net=int(P["use_res_net"]) > 0,
+               pixel_norm=int(P["pixelNorm"]) > 0, batch_norm=int(P["batchNorm"]) > 0, upsample_mode=int(P["upsampleMode"]),
+               add_bicubic=int(P["addBicubicUpsample"]) > 0)
+    path = checkpoint.model_path(base, test_no, model_no, ema=int(P["loadEmas"]) > 0)
+    try:
+        params = checkpoint.load(path)
+        print("Model restored from %s." % path)
+    except FileNotFoundError as e:
+        if not int(P["synthWeights"]):
+            fail(str(e))
+        params = None
+        print("no checkpoint, seeded synthetic weights (synthWeights 1)")
+    gen = multipass.Generator("growing_gen", cfg, params, prec=ops.parse_prec(P["prec"]), device="cuda:0",
+                              seed=int(P["randSeed"]))
+    out_name = {2: "density_low_t%04d_2x2" % test_no + "_%04d.uni", 1: "density_low_t%04d_1x1" % test_no + "_%04d.uni",
+                3: "density_low_0x0_%04d.uni"}[mode]
+    print('*****OUTPUT ONLY*****')
+    probe = sims + "sim_%04d/density_low_%04d.uni" % (from_sim, 0)
+    head_0, _ = uniio.readUni(probe if os.path.exists(probe) else sims + "sim_%04d/density_low_%04d.uni" % (from_sim, f0))
+    gen_uni = int(P["genUni"]) > 0
+    for layerno in range(f0, f1):
+        print(layerno)
+        t0 = time.time()
+        low = torch.as_tensor(np.ascontiguousarray(x_3d[layerno - f0])).to("cuda:0")
+        prev = None if x_2 is None else torch.as_tensor(np.ascontiguousarray(x_2[layerno - f0][..., 0])).to("cuda:0")
+        vol = multipass.single_pass_8x(gen, low, prev, up, ta, batch=2, apply_cutoff=gen_uni)
+        torch.cuda.synchronize()
+        print("time for network: {0:.6f}".format(time.time() - t0))
+        if gen_uni:
+            head = dict(head_0)
+            head['dimX'] = head['dimY'] = head['dimZ'] = s
+            uniio.writeUni(sims + '/sim_%04d/' % from_sim + out_name % layerno, head, vol.cpu().numpy())
+    print('Test finished, %d volumes written to %s.' % (f1 - f0, sims))
+
+
 if int(P["out"]) > 0:
-    fail("output mode of the 8x networks is GAN/multipassGAN-out.py")
+    output_main()
+    exit(0)
 upsampling_mode, upsampled_data = int(P["upsamplingMode"]), int(P["upsampledData"])
 if (upsampling_mode, upsampled_data) not in ((2, 0), (1, 1), (3, 1)) or int(P["dataDim"]) != 2:
     fail("training is implemented for the first network (upsamplingMode 2, upsampledData 0) and the second / third "

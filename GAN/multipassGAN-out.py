@@ -7,7 +7,11 @@ HIP path (volumes stay in HBM between the passes).
 Differences, all deliberate: weights come from ``model_%04d.ckpt.npz`` (see checkpoint.py);
 ``synthWeights 1`` (extra, optional) falls back to seeded random weights when a checkpoint is
 missing; PNG previews are skipped (scipy.misc.imsave no longer exists); three loaded networks
-run as three passes (the reference exits on an inverted check, :624-626).
+run as three passes (the reference exits on an inverted check, :624-626); ``prec`` selects the
+arithmetic (2 = MPG_PREC_F16F8, default; 3 = MPG_PREC_F16X3).  ``transposeAxis`` 0..3 pick the slicing
+axes of the passes exactly as :397-547 do, including what is broken there: the third pass of
+transposeAxis 2 raises the reference's IndexError (:542); ``add_adj_idcs2/3`` are ignored (the
+reference's code for them writes past the array it allocates, :488-500).
 """
 import os
 import sys
@@ -69,8 +73,8 @@ prec = _ops.parse_prec(prec)
 if useVorticities or useFlags or useK_Eps_Turb or usePixelShuffle:
     print("ERROR: vorticity / flag / turbulence channels and pixel shuffle are not part of the multi-pass hot path")
     exit(1)
-if transposeAxis != 0:
-    print("ERROR: only transposeAxis 0 (the example configuration) is implemented")
+if transposeAxis not in (0, 1, 2, 3):
+    print("ERROR: transposeAxis %d (0..3)" % transposeAxis)
     exit(1)
 os.environ.setdefault("HIP_VISIBLE_DEVICES", str(gpu))
 device = "cuda:0"
@@ -122,7 +126,7 @@ for layerno in range(frame_min, frame_max):
     print(layerno)
     start = time.time()
     low = torch.as_tensor(np.ascontiguousarray(x_3d[layerno - frame_min])).to(device)
-    vol = multipass.multipass_8x(gens, low, upRes, apply_cutoff=bool(generateUni))
+    vol = multipass.multipass_8x(gens, low, upRes, apply_cutoff=bool(generateUni), transpose_axis=transposeAxis)
     torch.cuda.synchronize()
     print("time for %d network(s): %.6f" % (len(gens), time.time() - start))
     if generateUni:

@@ -158,6 +158,30 @@ def _pass2_4x(gen2, low, v1, up_res, batch, comm, backend, vel_scale):
     return _start_gather(comm, out2, s)
 
 
+def refine_pass_4x(gen, low, prev, up_res=4, mode=1, batch=8, comm=None, backend=ops, vel_scale=1.0, apply_cutoff=True):
+    """One refining invocation of multipassGAN-4x.py (upsamplingMode 1: planes (z,y) along x, :1113-1119,1139-1142;
+    upsamplingMode 3: planes (z,x) along y, :1121-1124,1144).  prev: the [z,y,x] volume of the previous network.
+    Returns the [z,y,x] volume the reference writes (cutoff :1156-1157)."""
+    comm = comm or LocalComm()
+    nch = low.shape[3]
+    s = low.shape[0] * up_res
+    lo, hi = slice_range(s, comm)
+    # mode 1: transpose(0,3,1,2,4) + swaps 2<->3, 3<->1; mode 3: transpose(0,2,1,3,4) + swap 2<->3
+    perm, cmap, back = ((2, 0, 1), [0, 2, 3, 1], (1, 2, 0)) if mode == 1 else ((1, 0, 2), [0, 1, 3, 2], (1, 0, 2))
+    if nch > 1:
+        vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
+        if vel_scale != 1.0:
+            vel[..., 1:3] *= vel_scale                               # 4x.py:283 on the 3-channel array: vy,vz only
+        for ax in range(3):                                          # 4x.py:1095
+            vel = backend.axis_zoom_linear(vel, ax, up_res)
+        xin = backend.volume_transpose(torch.cat([prev.reshape(s, s, s, 1), vel], dim=3), perm, chan_map=cmap)
+    else:
+        xin = backend.volume_transpose(prev.reshape(s, s, s), perm).reshape(s, s, s, 1)
+    out = _run_pass(gen, xin, None, lo, hi, batch)
+    vol = comm.all_gather_slabs(out, s)
+    return backend.volume_transpose(vol, back, cutoff=CUTOFF if apply_cutoff else 0.0)
+
+
 def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
     """low: device [z,y,x,C].  Returns (final [z,y,x], pass-1 volume [z,y,x]), both with the
     <5e-4 cutoff of the files the reference writes between and after the passes."""
@@ -193,43 +217,107 @@ def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=op
 
 
 # ----------------------------------------------------------------------------
-# 8x: up to three networks in one process (multipassGAN-out.py:390-618, transposeAxis 0)
+# 8x: up to three networks in one process (multipassGAN-out.py:390-618)
 # ----------------------------------------------------------------------------
-def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops, apply_cutoff=True):
-    """gens: 1..3 Generator objects (first one firstGen).  low: device [z,y,x,4] with velocities
-    already scaled by velScale (out.py:138).  Returns the [z,y,x] density volume."""
-    comm = comm or LocalComm()
+# Low-res slice batch of pass p under `transposeAxis` t (multipassGAN-out.py:397-421, 463-485, 525-547):
+# (axis zoomed to the high resolution, axes order of the [z,y,x] volume, output channel k <- input channel map[k]).
+# The velocity component along the slicing axis trades places with vz; transposeAxis 3 rotates all three.
+_SWAP_YZ, _SWAP_XZ, _ROT3 = [0, 1, 3, 2], [0, 3, 2, 1], [0, 2, 3, 1]
+SLICE_PREP = {
+    1: {0: (0, None, None), 1: (1, (1, 0, 2), _SWAP_YZ), 2: (2, (2, 1, 0), _SWAP_XZ), 3: (2, (2, 0, 1), _ROT3)},
+    2: {0: (2, (2, 1, 0), _SWAP_XZ), 1: (2, (2, 0, 1), _ROT3), 2: (0, None, None), 3: (1, (1, 0, 2), _SWAP_YZ)},
+    # pass 3: transposeAxis 2 reads channel 13 of a 4-channel batch in the reference (:542) -> IndexError there too;
+    # transposeAxis 3 regroups a [z, X, y] array into sim x sim planes without moving X to the front (:534-535)
+    3: {0: (1, (1, 0, 2), _SWAP_YZ), 1: (0, None, None), 3: (2, (0, 2, 1), [0, 2, 1, 3])},
+}
+
+
+def slice_batch_8x(low, up_res, pass_no, transpose_axis, backend=ops):
+    """[S, sim, sim, C] low-res slice batch of one pass (before the add_adj_idcs channels)"""
     sim, nch = low.shape[0], low.shape[3]
+    try:
+        axis, perm, cmap = SLICE_PREP[pass_no][transpose_axis]
+    except KeyError:
+        if pass_no == 3 and transpose_axis == 2:
+            raise IndexError("index 13 is out of bounds for axis 3 with size %d (multipassGAN-out.py:542: the third "
+                             "pass of transposeAxis 2 is broken in the reference as well)" % nch)
+        raise ValueError("transposeAxis %r (0..3)" % (transpose_axis,))
+    xs = backend.axis_zoom_linear(low, axis, up_res)
+    if perm is not None:
+        xs = backend.volume_transpose(xs, perm, chan_map=cmap if nch >= 4 else None)
+    return xs.reshape(-1, sim, sim, nch)
+
+
+def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops, apply_cutoff=True, transpose_axis=0):
+    """gens: 1..3 Generator objects (first one firstGen).  low: device [z,y,x,4] with velocities
+    already scaled by velScale (out.py:138).  Returns the density volume after the reference's final
+    axis restore (:587-590): [z,y,x] for transposeAxis 0."""
+    comm = comm or LocalComm()
+    sim = low.shape[0]
     s = sim * up_res
     lo, hi = slice_range(s, comm)
-    # pass 1 (397-461): zoom z, slices along z, add_adj_idcs channels
-    xs = backend.axis_zoom_linear(low, 0, up_res)
+    # pass 1 (397-461): slices along the zoomed axis, add_adj_idcs channels
+    xs = slice_batch_8x(low, up_res, 1, transpose_axis, backend)
     if gens[0].cfg.get("add_adj", False):
         xs_r = backend.add_adjacent(xs, lo, hi - lo)
         out = _run_pass(gens[0], xs_r, None, 0, hi - lo, batches[0])
     else:
         out = _run_pass(gens[0], xs, None, lo, hi, batches[0])
-    vol = comm.all_gather_slabs(out, s)                                  # (z, y, x)
-    order = "zyx"
+    vol = comm.all_gather_slabs(out, s)
     if len(gens) > 1:
-        # pass 2 (463-523): planes (y,z) along x.  dim_output.transpose(2,1,0) (:459)
-        ys = backend.volume_transpose(vol, (2, 1, 0))                    # (x, y, z)
-        xl = backend.axis_zoom_linear(low, 2, up_res)                    # [z, y, S, C]
-        xl = backend.volume_transpose(xl, (2, 1, 0), chan_map=[0, 3, 2, 1])   # :472-475
+        # pass 2 (463-523): conditioned on planes of dim_output.transpose(2,1,0) (:459)
+        ys = backend.volume_transpose(vol, (2, 1, 0))
+        xl = slice_batch_8x(low, up_res, 2, transpose_axis, backend)
         out = _run_pass(gens[1], xl, ys, lo, hi, batches[1])
-        vol = comm.all_gather_slabs(out, s)                              # (x, y, z)
-        order = "xyz"
+        vol = comm.all_gather_slabs(out, s)
     if len(gens) > 2:
-        # pass 3 (525-585): planes (z,x) along y.  previous result .transpose(1,2,0) (:521) -> (y,z,x)
-        ys = backend.volume_transpose(vol, (1, 2, 0))                    # (y, z, x)
-        xl = backend.axis_zoom_linear(low, 1, up_res)                    # [z, S, x, C]
-        xl = backend.volume_transpose(xl, (1, 0, 2), chan_map=[0, 1, 3, 2])   # :528-531
+        # pass 3 (525-585): conditioned on the previous result .transpose(1,2,0) (:521)
+        ys = backend.volume_transpose(vol, (1, 2, 0))
+        xl = slice_batch_8x(low, up_res, 3, transpose_axis, backend)
         out = _run_pass(gens[2], xl, ys, lo, hi, batches[2])
-        vol = comm.all_gather_slabs(out, s)                              # (y, z, x)
-        order = "yzx"
-    # final axis restore (587-590) and cutoff (614-615)
+        vol = comm.all_gather_slabs(out, s)
+    # the transposes the reference applies to its last dim_output, composed (459 / 521 / 583, then 587-590)
+    perm = {1: (0, 1, 2), 2: (2, 1, 0), 3: (1, 0, 2)}[len(gens)]
     thr = CUTOFF if apply_cutoff else 0.0
-    perm = {"zyx": (0, 1, 2), "xyz": (2, 1, 0), "yzx": (1, 0, 2)}[order]
     if perm == (0, 1, 2):
         return backend.cutoff(vol, CUTOFF) if apply_cutoff else vol
     return backend.volume_transpose(vol, perm, cutoff=thr)
+
+
+# ----------------------------------------------------------------------------
+# 8x: one network per process, volumes travel through .uni files (multipassGAN-8x.py:1600-1780;
+# the commented alternative of example_run_output.py:64-70: modes 2 -> 1 -> 3)
+# ----------------------------------------------------------------------------
+# (axes order applied to the slice batch and to the previous volume, channel map, order that restores [z,y,x])
+_SINGLE_PASS = {0: (None, None, (0, 1, 2)), 1: ((1, 0, 2), _SWAP_YZ, (1, 0, 2)), 2: ((2, 1, 0), _SWAP_XZ, (2, 1, 0)),
+                3: ((2, 0, 1), _ROT3, (1, 2, 0))}
+_ZOOM_AXIS = {0: 0, 1: 1, 2: 2, 3: 2}
+
+
+def single_pass_8x(gen, low, prev=None, up_res=8, transpose_axis=0, batch=2, comm=None, backend=ops, apply_cutoff=True):
+    """One `multipassGAN-8x.py out 1` invocation.  low: device [z,y,x,C]; prev: None for the first network
+    (upsamplingMode 2) or the previous network's [z,y,x] volume as stored in its .uni file (modes 1 / 3).
+    Returns the volume the reference writes: [z,y,x] with the <5e-4 cutoff (:1720-1725, 1766-1767)."""
+    comm = comm or LocalComm()
+    sim, nch = low.shape[0], low.shape[3]
+    s = sim * up_res
+    lo, hi = slice_range(s, comm)
+    perm, cmap, back = _SINGLE_PASS[transpose_axis]
+    xs = backend.axis_zoom_linear(low, _ZOOM_AXIS[transpose_axis], up_res)           # :1606-1613, 1624-1631
+    if perm is not None:
+        xs = backend.volume_transpose(xs, perm, chan_map=cmap if nch >= 4 else None)  # :1644-1664
+    xs = xs.reshape(-1, sim, sim, nch)
+    ys = None
+    if prev is not None:
+        ys = prev.reshape(s, s, s)
+        if perm is not None:
+            ys = backend.volume_transpose(ys, perm)                                  # :1650,1657,1666
+    if gen.cfg.get("add_adj", False):
+        out = _run_pass(gen, backend.add_adjacent(xs, lo, hi - lo), ys[lo:hi] if ys is not None else None, 0, hi - lo, batch)
+    else:
+        out = _run_pass(gen, xs, ys, lo, hi, batch)
+    vol = comm.all_gather_slabs(out, s)
+    thr = CUTOFF if apply_cutoff else 0.0
+    if back == (0, 1, 2):
+        return backend.cutoff(vol, CUTOFF) if apply_cutoff else vol
+    return backend.volume_transpose(vol, back, cutoff=thr)

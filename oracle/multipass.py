@@ -83,6 +83,32 @@ def pass2_4x(ps, x2, low, up_res=4, batch_norm=True, vel_scale=1.0):
     return cutoff(out.reshape(s, s, s).transpose(1, 2, 0))
 
 
+def pass3_input_4x(x2, low, up_res=4, vel_scale=1.0):
+    """slice batch of ``upsamplingMode 3`` (4x.py:278-283,1095,1121-1124): [y][z][x] planes of (second-pass
+    density, velocities*upRes zoomed in all axes), channels (d, vx, vz, vy) after the one swap."""
+    s = x2.shape[0]
+    if low.shape[-1] > 1:
+        vel = low[..., 1:4].astype(F32) * F32(up_res)            # :278
+        vel[..., 1:4] = F32(vel_scale) * vel[..., 1:4]            # :283 (acts on vy,vz only)
+        for ax in range(3):                                       # :1095
+            vel = ops.zoom_axis_linear(vel, ax, up_res)
+        vol = np.concatenate([x2.reshape(s, s, s, 1), vel], axis=3)
+    else:
+        vol = x2.reshape(s, s, s, 1)
+    nch = vol.shape[-1]
+    xs = vol.reshape(1, s, s, s, nch).transpose(0, 2, 1, 3, 4).reshape(-1, s, s, nch).copy()    # :1121
+    if nch >= 4:
+        swap_channels(xs, 2, 3)                                   # :1122-1124
+    return xs
+
+
+def pass3_4x(ps, x2, low, up_res=4, batch_norm=True, vel_scale=1.0):
+    """``upsamplingMode 3``: refine along y; result back to [z,y,x] and cut off (4x.py:1144,1156-1157)."""
+    s = x2.shape[0]
+    out = nets.gen_resnet(ps, pass3_input_4x(x2, low, up_res, vel_scale), up_res, 3, batch_norm)
+    return cutoff(out.reshape(s, s, s).transpose(1, 0, 2))
+
+
 def two_pass_4x(ps1, ps2, low, up_res=4, batch_norm=True, vel_scale=1.0):
     """C1/C2 of BASELINE.json: the two ``multipassGAN-4x.py out 1`` runs of
     example_run_output.py:4-8 chained through the intermediate volume."""
@@ -96,45 +122,114 @@ def two_pass_4x(ps1, ps2, low, up_res=4, batch_norm=True, vel_scale=1.0):
 
 
 # ----------------------------------------------------------------------------
-# 8x, up to three networks in one process (multipassGAN-out.py:390-618), transposeAxis 0
+# 8x, up to three networks in one process (multipassGAN-out.py:390-618)
 # ----------------------------------------------------------------------------
-def multipass_8x(ps_list, cfgs, low, up_res=8, pixel_norm=True, apply_cutoff=True):
-    """``generate3DUniForNewNetwork`` of multipassGAN-out.py for
-    ``transposeAxis 0``.  ps_list/cfgs: one entry per loaded network (2 or 3);
-    cfg keys: filter_size, start_fms, max_fms, add_adj, first_nn_arch, use_res_net.
+def _gen_cfg(ps, c, xin, up_res, first, pixel_norm):
+    return nets.growing_gen(ps, xin, up_res, first, c["filter_size"], c["start_fms"], c["max_fms"],
+                            c.get("first_nn_arch", False) if first else False, c.get("use_res_net", True), pixel_norm)
+
+
+def slice_batch_8x(low, up_res, pass_no, transpose_axis):
+    """the low-res slice batch of one pass for a given ``transposeAxis``, written as the reference writes it:
+    pass 1 :397-421, pass 2 :463-485, pass 3 :525-547"""
+    sim = low.shape[0]
+    nch = low.shape[-1]
+    ta = transpose_axis
+
+    def zoomed(axis):
+        return ops.zoom_axis_linear(low, axis, up_res)
+
+    def planes(a, order):
+        return np.ascontiguousarray(a.transpose(order + (3,))).reshape(-1, sim, sim, nch)
+
+    # which branch of the if-chain the pass takes: the reference rotates the roles of the four values
+    kind = {1: {1: "y", 2: "x", 3: "x3", 0: "z"}, 2: {3: "y", 0: "x", 1: "x3", 2: "z"},
+            3: {0: "y", 3: "x_odd", 2: "broken", 1: "z"}}[pass_no][ta]
+    if kind == "z":
+        return zoomed(0).reshape(-1, sim, sim, nch)
+    if kind == "y":
+        xs = planes(zoomed(1), (1, 0, 2))
+        return swap_channels(xs, 3, 2) if nch >= 4 else xs
+    if kind == "x":
+        xs = planes(zoomed(2), (2, 1, 0))
+        return swap_channels(xs, 3, 1) if nch >= 4 else xs
+    if kind == "x3":
+        xs = planes(zoomed(2), (2, 0, 1))
+        if nch >= 4:
+            t3, t2 = np.copy(xs[..., 3]), np.copy(xs[..., 2])
+            xs[..., 3] = xs[..., 1]
+            xs[..., 2] = t3
+            xs[..., 1] = t2
+        return xs
+    if kind == "x_odd":
+        xs = planes(zoomed(2), (0, 2, 1))                                        # :534-535
+        return swap_channels(xs, 2, 1) if nch >= 4 else xs
+    raise IndexError("index 13 is out of bounds for axis 3 with size %d" % nch)   # :542
+
+
+def multipass_8x(ps_list, cfgs, low, up_res=8, pixel_norm=True, apply_cutoff=True, transpose_axis=0):
+    """``generate3DUniForNewNetwork`` of multipassGAN-out.py.  ps_list/cfgs: one entry per loaded network
+    (1..3); cfg keys: filter_size, start_fms, max_fms, add_adj, first_nn_arch, use_res_net.
     low: [z,y,x,4] with velocities already scaled by velScale (:138)."""
     sim = low.shape[0]
     s = sim * up_res
     nch = low.shape[-1]
-    dim_output = None
-    # pass 1 (397-461)
-    xs = ops.zoom_axis_linear(low, 0, up_res).reshape(-1, sim, sim, nch)
+    xs = slice_batch_8x(low, up_res, 1, transpose_axis)
     c = cfgs[0]
     if c.get("add_adj", False):
         xs = add_adjacent(xs, nch)
-    out = nets.growing_gen(ps_list[0], xs, up_res, True, c["filter_size"], c["start_fms"], c["max_fms"],
-                           c.get("first_nn_arch", False), c.get("use_res_net", True), pixel_norm)
-    dim_output = out.reshape(s, s, s).transpose(2, 1, 0)                         # :459 -> (x,y,z)
-    # pass 2 (463-523)
+    out = _gen_cfg(ps_list[0], c, xs, up_res, True, pixel_norm)
+    dim_output = out.reshape(s, s, s).transpose(2, 1, 0)                         # :459
     if len(ps_list) > 1:
-        c = cfgs[1]
-        xs = ops.zoom_axis_linear(low, 2, up_res).transpose(2, 1, 0, 3).copy()   # :471-472
-        swap_channels(xs, 3, 1)                                                  # :473-475
-        xin = nets.gen2_input(dim_output.reshape(s, s, s, 1), xs, s)
-        out = nets.growing_gen(ps_list[1], xin, up_res, False, c["filter_size"], c["start_fms"], c["max_fms"],
-                               False, c.get("use_res_net", True), pixel_norm)
-        dim_output = out.reshape(s, s, s).transpose(1, 2, 0)                     # :521 -> (y,z,x)
-    # pass 3 (525-585)
+        xs = slice_batch_8x(low, up_res, 2, transpose_axis)
+        xin = nets.gen2_input(np.ascontiguousarray(dim_output).reshape(s, s, s, 1), xs, s)
+        out = _gen_cfg(ps_list[1], cfgs[1], xin, up_res, False, pixel_norm)
+        dim_output = out.reshape(s, s, s).transpose(1, 2, 0)                     # :521
     if len(ps_list) > 2:
-        c = cfgs[2]
-        xs = ops.zoom_axis_linear(low, 1, up_res).transpose(1, 0, 2, 3).copy()   # :527-528
-        swap_channels(xs, 3, 2)                                                  # :529-531
-        xin = nets.gen2_input(dim_output.reshape(s, s, s, 1), xs, s)
-        out = nets.growing_gen(ps_list[2], xin, up_res, False, c["filter_size"], c["start_fms"], c["max_fms"],
-                               False, c.get("use_res_net", True), pixel_norm)
+        xs = slice_batch_8x(low, up_res, 3, transpose_axis)
+        xin = nets.gen2_input(np.ascontiguousarray(dim_output).reshape(s, s, s, 1), xs, s)
+        out = _gen_cfg(ps_list[2], cfgs[2], xin, up_res, False, pixel_norm)
         dim_output = out.reshape(s, s, s)                                        # :583
     if len(ps_list) > 1:
         dim_output = dim_output.transpose(2, 0, 1)                               # :587-588
     dim_output = dim_output.transpose(2, 1, 0)                                   # :589-590
     dim_output = np.ascontiguousarray(dim_output)
     return cutoff(dim_output) if apply_cutoff else dim_output
+
+
+# ----------------------------------------------------------------------------
+# 8x, one network per process (multipassGAN-8x.py:1600-1780)
+# ----------------------------------------------------------------------------
+def single_pass_8x(ps, cfg, low, prev=None, up_res=8, transpose_axis=0, pixel_norm=True, apply_cutoff=True):
+    """one ``multipassGAN-8x.py out 1`` run: prev None = upsamplingMode 2 (first network), else the previous
+    network's [z,y,x] volume (modes 1 / 3).  Returns the volume written to the .uni file."""
+    sim = low.shape[0]
+    s = sim * up_res
+    nch = low.shape[-1]
+    ta = transpose_axis
+    axis = {0: 0, 1: 1, 2: 2, 3: 2}[ta]                                           # :1606-1613 / 1624-1631
+    xs = ops.zoom_axis_linear(low, axis, up_res)
+    order = {0: None, 1: (1, 0, 2), 2: (2, 1, 0), 3: (2, 0, 1)}[ta]
+    ys = None if prev is None else np.asarray(prev, dtype=F32).reshape(s, s, s, 1)
+    if order is not None:                                                        # :1644-1666
+        xs = np.ascontiguousarray(xs.transpose(order + (3,)))
+        if ys is not None:
+            ys = np.ascontiguousarray(ys.transpose(order + (3,)))
+    xs = xs.reshape(-1, sim, sim, nch)
+    if nch >= 4:
+        if ta == 1:
+            swap_channels(xs, 3, 2)
+        elif ta == 2:
+            swap_channels(xs, 3, 1)
+        elif ta == 3:
+            t3, t2 = np.copy(xs[..., 3]), np.copy(xs[..., 2])
+            xs[..., 3] = xs[..., 1]
+            xs[..., 2] = t3
+            xs[..., 1] = t2
+    if cfg.get("add_adj", False):
+        xs = add_adjacent(xs, nch)                                               # :1671-1685
+    xin = xs if ys is None else nets.gen2_input(ys.reshape(s, s, s, 1), xs, s)
+    out = _gen_cfg(ps, cfg, xin, up_res, prev is None, pixel_norm).reshape(s, s, s)
+    back = {0: (0, 1, 2), 1: (1, 0, 2), 2: (2, 1, 0), 3: (1, 2, 0)}[ta]           # :1720-1725
+    out = np.ascontiguousarray(out.transpose(back))
+    return cutoff(out) if apply_cutoff else out

@@ -57,14 +57,20 @@ def test_4x_two_invocations(tmp_path, vel):
                                          "upsamplingMode", 2, "upsampledData", 0], str(tmp_path))
     _run("multipassGAN-4x.py", common + ["randSeed", 102, "load_model_test", 48, "load_model_no", 799,
                                          "upsamplingMode", 1, "upsampledData", 1], str(tmp_path))
+    # third network (upsamplingMode 3: planes (z,x) along y), reads density_low_1x1, writes density_low_0x0
+    _run("multipassGAN-4x.py", common + ["randSeed", 103, "load_model_test", 48, "load_model_no", 800,
+                                         "upsamplingMode", 3, "upsampledData", 1], str(tmp_path))
     for f in range(2):
         low = vols[f] if vel else vols[f][..., 0:1]
         ref, ref1 = OM.two_pass_4x(ON.ParamSource(seed=101), ON.ParamSource(seed=102), low, up, True)
+        ref3 = OM.pass3_4x(ON.ParamSource(seed=103), ref, low, up, True)
         h1, v1 = uniio.readUni(str(tmp_path / "data" / "sim_1005" / ("density_low_2x2_%04d.uni" % f)))
         h2, v2 = uniio.readUni(str(tmp_path / "data" / "sim_1005" / ("density_low_1x1_%04d.uni" % f)))
+        h3, v3 = uniio.readUni(str(tmp_path / "data" / "sim_1005" / ("density_low_0x0_%04d.uni" % f)))
         assert (h2["dimX"], h2["dimY"], h2["dimZ"]) == (32, 32, 32) and v2.shape == (32, 32, 32, 1)
         assert rel_l2(v1[..., 0], ref1) < tol
         assert rel_l2(v2[..., 0], ref) < tol
+        assert v3.shape == (32, 32, 32, 1) and rel_l2(v3[..., 0], ref3) < 2 * tol
 
 
 def test_8x_out_driver(tmp_path):
@@ -94,6 +100,85 @@ def test_8x_out_driver(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "GAN", "multipassGAN-out.py"), "nonsense", "1"],
                        capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "not used" in r.stdout
+
+
+NET_ARGS_8X = ["use_res_net1", 1, "add_adj_idcs1", 1, "startFms1", 256, "maxFms1", 256, "filterSize1", 3,
+               "use_res_net2", 1, "add_adj_idcs2", 0, "startFms2", 192, "maxFms2", 192, "filterSize2", 5,
+               "use_res_net3", 0, "add_adj_idcs3", 0, "startFms3", 192, "maxFms3", 96, "filterSize3", 5]
+CFGS_8X = [dict(filter_size=3, start_fms=256, max_fms=256, add_adj=True, first_nn_arch=True, use_res_net=True),
+           dict(filter_size=5, start_fms=192, max_fms=192, use_res_net=True),
+           dict(filter_size=5, start_fms=192, max_fms=96, use_res_net=False)]
+
+
+@pytest.mark.parametrize("ta,nets", [(1, 3), (2, 2), (3, 2)])
+def test_8x_out_driver_transpose_axis(tmp_path, ta, nets):
+    """multipassGAN-out.py with transposeAxis 1 / 2 / 3 (slicing axes per pass as :397-547), fp32-grade arithmetic"""
+    from mpgan_amd import uniio
+    sim, up = 4, 8
+    vols = _make_sim(tmp_path, sim, 1, 1)
+    for t in (0, 7):
+        (tmp_path / "models" / ("test_%04d" % t)).mkdir()
+    loaded = [("load_model_test_%d" % (k + 1), (0, 4, 7)[k] if k < nets else -1) for k in range(3)]
+    args = ["randSeed", 300, "upRes", up, "pixelNorm", 1, "batchNorm", 0, "out", 1, "tileSize", sim, "simSize", sim,
+            "fromSim", 1005, "useVelocities", 1, "basePath", str(tmp_path / "models") + "/",
+            "packedSimPath", str(tmp_path / "data") + "/", "frame_max", 1, "frame_min", 0, "velScale", 1.0, "genUni", 1,
+            "upsampleMode", 1, "addBicubicUpsample", 1, "transposeAxis", ta, "firstNNArch", 1, "synthWeights", 1, "prec", 3,
+            "load_model_no_1", 1, "load_model_no_2", 2, "load_model_no_3", 3 if nets > 2 else -1] + NET_ARGS_8X
+    for k, v in loaded:
+        args += [k, v]
+    _run("multipassGAN-out.py", args, str(tmp_path))
+    ref = OM.multipass_8x([ON.ParamSource(seed=300 + k) for k in range(nets)], CFGS_8X[:nets], vols[0], up, transpose_axis=ta)
+    h, v = uniio.readUni(str(tmp_path / "data" / "sim_1005" / "source_0000.uni"))
+    assert v.shape == (32, 32, 32, 1)
+    assert rel_l2(v[..., 0], ref) < 1e-4
+
+
+def test_8x_out_driver_transpose_axis_2_third_pass_fails_like_the_reference(tmp_path):
+    """multipassGAN-out.py:542 indexes channel 13 of a 4-channel batch: IndexError"""
+    sim, up = 4, 8
+    _make_sim(tmp_path, sim, 1, 1)
+    for t in (0, 7):
+        (tmp_path / "models" / ("test_%04d" % t)).mkdir()
+    args = ["randSeed", 300, "upRes", up, "out", 1, "tileSize", sim, "simSize", sim, "fromSim", 1005, "useVelocities", 1,
+            "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/", "frame_max", 1,
+            "frame_min", 0, "genUni", 1, "addBicubicUpsample", 1, "transposeAxis", 2, "firstNNArch", 1, "synthWeights", 1,
+            "load_model_test_1", 0, "load_model_no_1", 1, "load_model_test_2", 4, "load_model_no_2", 2,
+            "load_model_test_3", 7, "load_model_no_3", 3] + NET_ARGS_8X
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "GAN", "multipassGAN-out.py")] + [str(a) for a in args],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "IndexError" in r.stderr
+
+
+def test_8x_single_network_invocations(tmp_path):
+    """the per-network alternative of example_run_output.py:64-70: three `multipassGAN-8x.py out 1` runs (modes 2 -> 1 -> 3,
+    transposeAxis 0 / 2 / 1) chained through density_low_t%04d_2x2 / _1x1 / density_low_0x0 files"""
+    from mpgan_amd import uniio
+    sim, up = 4, 8
+    vols = _make_sim(tmp_path, sim, 1, 1)
+    for t in (0, 9, 11):
+        (tmp_path / "models" / ("test_%04d" % t)).mkdir(exist_ok=True)
+    common = ["upRes", up, "pixelNorm", 1, "batchNorm", 0, "out", 1, "tileSize", sim, "simSize", sim, "fromSim", 1005,
+              "toSim", 1005, "dataDim", 2, "useVelocities", 1, "basePath", str(tmp_path / "models") + "/",
+              "packedSimPath", str(tmp_path / "data") + "/", "frame_max", 1, "frame_min", 0, "velScale", 1.0, "genUni", 1,
+              "upsampleMode", 1, "addBicubicUpsample", 1, "synthWeights", 1, "prec", 3, "genModel", "gen_resnet"]
+    _run("multipassGAN-8x.py", common + ["randSeed", 400, "use_res_net", 1, "firstNNArch", 1, "add_adj_idcs", 1,
+                                         "load_model_test", 0, "load_model_no", 299, "upsampledData", 0, "upsamplingMode", 2,
+                                         "maxFms", 256, "startFms", 256, "filterSize", 3, "transposeAxis", 0], str(tmp_path))
+    _run("multipassGAN-8x.py", common + ["randSeed", 401, "use_res_net", 1, "outNNTestNo", 0, "load_model_test", 9,
+                                         "load_model_no", 499, "upsampledData", 1, "upsamplingMode", 1, "maxFms", 192,
+                                         "startFms", 192, "filterSize", 5, "transposeAxis", 2], str(tmp_path))
+    _run("multipassGAN-8x.py", common + ["randSeed", 402, "use_res_net", 0, "outNNTestNo", 9, "load_model_test", 11,
+                                         "load_model_no", 749, "upsampledData", 1, "upsamplingMode", 3, "maxFms", 96,
+                                         "startFms", 192, "filterSize", 5, "transposeAxis", 1], str(tmp_path))
+    d = tmp_path / "data" / "sim_1005"
+    w1 = OM.single_pass_8x(ON.ParamSource(seed=400), CFGS_8X[0], vols[0], None, up, 0)
+    w2 = OM.single_pass_8x(ON.ParamSource(seed=401), CFGS_8X[1], vols[0], w1, up, 2)
+    w3 = OM.single_pass_8x(ON.ParamSource(seed=402), CFGS_8X[2], vols[0], w2, up, 1)
+    for name, want in (("density_low_t0000_2x2_0000.uni", w1), ("density_low_t0009_1x1_0000.uni", w2),
+                       ("density_low_0x0_0000.uni", w3)):
+        h, v = uniio.readUni(str(d / name))
+        assert v.shape == (32, 32, 32, 1) and h["dimZ"] == 32, name
+        assert rel_l2(v[..., 0], want) < 1e-4, name
 
 
 @pytest.mark.parametrize("lambda_t", [0.0, 1.0])

@@ -137,6 +137,41 @@ def test_multipass_8x_small(MP, mpg, prec, nets):
     assert rel_l2(out.cpu().numpy(), ref) < TOL[prec], rel_l2(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("ta", [1, 2, 3])
+def test_multipass_8x_transpose_axis(MP, mpg, ta):
+    """the slicing axes of multipassGAN-out.py:397-547 for transposeAxis 1..3 (default arithmetic), and the
+    per-network path of multipassGAN-8x.py:1600-1780 on the same generators"""
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, up = 4, 8
+    low = synthetic_volume(sim, 4, 2)
+    pss = [ON.ParamSource(seed=61 + i) for i in range(2)]
+    cfgs = [NET_CFGS["net1"], NET_CFGS["net2"]]
+    ref = OM.multipass_8x(pss, cfgs, low, up, transpose_axis=ta)
+    gens = [MP.Generator("growing_gen", dict(tile_low=sim, up_res=up, channels=4, **c), ps.params) for c, ps in zip(cfgs, pss)]
+    out = MP.multipass_8x(gens, _t(low), up, transpose_axis=ta)
+    assert rel_l2(out.cpu().numpy(), ref) < TOL[2]
+    w1 = OM.single_pass_8x(pss[0], cfgs[0], low, None, up, ta)
+    w2 = OM.single_pass_8x(pss[1], cfgs[1], low, w1, up, ta)
+    v1 = MP.single_pass_8x(gens[0], _t(low), None, up, ta)
+    v2 = MP.single_pass_8x(gens[1], _t(low), v1, up, ta)
+    assert rel_l2(v1.cpu().numpy(), w1) < TOL[2] and rel_l2(v2.cpu().numpy(), w2) < TOL[2]
+
+
+def test_three_pass_4x(MP, mpg):
+    """third 4x network (upsamplingMode 3, multipassGAN-4x.py:1121-1124,1144)"""
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, up = 8, 4
+    low = synthetic_volume(sim, 4, 0)
+    ps = [ON.ParamSource(seed=71 + i) for i in range(3)]
+    ref2, _ = OM.two_pass_4x(ps[0], ps[1], low, up, True, 0.7)
+    ref3 = OM.pass3_4x(ps[2], ref2, low, up, True, 0.7)
+    gens = [MP.Generator("gen_resnet", dict(tile_low=sim, up_res=up, channels=4, upsampling_mode=m), p.params, 3)
+            for m, p in zip((2, 1, 3), ps)]
+    out2, _ = MP.two_pass_4x(gens[0], gens[1], _t(low), up, vel_scale=0.7)
+    out3 = MP.refine_pass_4x(gens[2], _t(low), out2, up, mode=3, vel_scale=0.7)
+    assert rel_l2(out3.cpu().numpy(), ref3) < 2e-4
+
+
 @pytest.mark.parametrize("nch", [1, 4])
 def test_disc_binclass_forward(mpg, nch):
     """4x spatial discriminator forward (multipassGAN-4x.py:572-620): strided 4x4 convs, batch norm
