@@ -203,6 +203,17 @@ int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_total, size_t h
 /* out[i] = v[i] < cutoff ? 0 : v[i]   (multipassGAN-4x.py:1156-1157) */
 int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out);
 
+/* tf.nn.conv2d_transpose(x, W, output_shape = [n, h*stride_h, w*stride_w, cout], strides, "SAME") + bias + activation:
+ * GAN.deconv2d / GAN.deconvolutional_layer (GAN.py:566-619, 703-708).  w_hwoi[kh,kw,cout,cin] is TensorFlow's
+ * transposed-convolution filter layout (output channels before input channels).  y[n, h*stride_h, w*stride_w, cout].
+ * fp32 vector-ALU gather, any stride / filter; the matrix-core route for stride 1 and 2 is composed above the ABI from
+ * mpg_conv2d_fused (flipped / sub-pixel filters) and mpg_depth_to_space (ops.conv2d_transpose). */
+int mpg_conv2d_transpose(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* w_hwoi,
+                         int kh, int kw, int cout, int stride_h, int stride_w, float wscale, const float* bias,
+                         int act, float leak, float* y);
+/* tf.depth_to_space(x, r) (GAN.pixel_shuffle, GAN.py:554-560): x[n,h,w,c] -> y[n, h*r, w*r, c / r^2] */
+int mpg_depth_to_space(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int r, float* y);
+
 /* ------------------------------------------------------------------------
  * Training step: what tf.gradients produces for
  * the layers of GAN.py, and the optimiser update.  fp32 NHWC device tensors;

@@ -171,15 +171,51 @@ class GAN(object):
         _say("Avg Depool {}: {}".format(window_size, self.layer.get_shape()))
         return self.layer
 
-    # GAN.py:554-560
+    # GAN.py:554-560: a 3x3 linear convolution to depth_factor^2 * C channels, then tf.depth_to_space
     def pixel_shuffle(self, input_layer=None, upres=2, stage="1"):
-        raise NotImplementedError("pixel_shuffle: usePixelShuffle is 0 in every reference run (example_run_output.py:48)")
+        if input_layer is None:
+            input_layer = self.layer
+        out_ch = int(input_layer.get_shape()[-1])
+        self.convolutional_layer(out_ch * upres * upres, [3, 3], None, stride=[1], name="g_cPS" + stage,
+                                 in_layer=input_layer)
+        self.layer = G.depth_to_space(self.layer, upres)
+        return self.layer
 
-    # GAN.py:566-619: unusable in the reference itself (weight_variable has no init_mean parameter, GAN.py:584,661)
+    # GAN.py:566-619, deconv2d :703-708.  As written, the reference cannot execute this method: it passes `init_mean` to
+    # weight_variable, which has no such parameter (GAN.py:584 vs :661) -- a TypeError before any graph is built, so
+    # there is no reference behaviour to diverge from.  Here the call works: tf.nn.conv2d_transpose with
+    # output_shape [N, H*stride, W*stride, outChannels], filter [kh,kw,outChannels,inChannels], SAME; `init_mean` is
+    # accepted (1.0 tags the scope name like the reference does) and `strideOverride` replaces the op's strides.
     def deconvolutional_layer(self, outChannels, _patchShape, activation_function=G.tanh, stride=[1], name="deconv",
                               reuse=False, batch_norm=False, train=None, init_mean=0., strideOverride=None):
-        raise TypeError("weight_variable() got an unexpected keyword argument 'init_mean' "
-                        "(same failure as the reference, tools_wscale/GAN.py:584)")
+        if init_mean == 1.:
+            name = name + "_EXCLUDE_ME_"
+        if len(_patchShape) != 2:
+            raise NotImplementedError("only 2D patches: the multi-pass path is slice-wise (GAN.py:591-598 is the 3D branch)")
+        with G.variable_scope(name, reuse=reuse):
+            self.layer_num += 1
+            inChannels = int(self.layer.get_shape()[-1])
+            st = list(stride) * 2 if len(stride) == 1 else list(stride)
+            dc = st if strideOverride is None else (list(strideOverride) * 2 if len(strideOverride) == 1 else list(strideOverride))
+            if dc != st:
+                raise NotImplementedError("strideOverride different from stride: output_shape and strides would disagree")
+            shape = [_patchShape[0], _patchShape[1], outChannels, inChannels]
+            W, wscale = self.weight_variable(shape, name=name)
+            self.layer = G.conv2d_transpose(self.layer, W, (st[0], st[1]), wscale)
+            self.DOFs += _patchShape[0] * _patchShape[1] * outChannels * inChannels
+            b = self.bias_variable([outChannels], name=name)
+            self.layer = G.bias_add(self.layer, b)
+            self.DOFs += outChannels
+            if batch_norm:
+                gamma = G.get_variable("gamma", [outChannels], "gamma")
+                beta = G.get_variable("beta", [outChannels], "beta")
+                mean = G.get_variable("moving_mean", [outChannels], "moving_mean")
+                var = G.get_variable("moving_variance", [outChannels], "moving_variance")
+                self.layer = G.batch_norm(self.layer, gamma, beta, mean, var, eps=1e-3, training=bool(train))
+            layer_lin = self.layer
+            if G.activation_name(activation_function):
+                self.layer = activation_function(self.layer)
+            return self.layer, layer_lin
 
     # GAN.py:624-631
     def noise(self, channels=-1):

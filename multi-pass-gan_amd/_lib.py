@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmpgan_hip.so")
+# development only (tools/probe_variants.py): time another build of the same library; never a fallback
+if os.environ.get("MPGAN_LIB_OVERRIDE"):
+    LIB_PATH = os.path.abspath(os.environ["MPGAN_LIB_OVERRIDE"])
 
 MPG_OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -99,6 +102,8 @@ PROTOTYPES = {
     "mpg_volume_transpose": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P]),
     "mpg_add_adjacent": (_I, [_P, _P, _I, _Z, _I, _I, _I, _P]),
     "mpg_cutoff": (_I, [_P, _P, _Z, _F, _P]),
+    "mpg_conv2d_transpose": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _I, _F, _P]),
+    "mpg_depth_to_space": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     # training step
     "mpg_conv2d_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_conv2d_wgrad_mfma_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),

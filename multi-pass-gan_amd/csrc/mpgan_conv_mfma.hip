@@ -21,6 +21,7 @@
 // + nearest upsample, + channel concat) of tools_wscale/GAN.py:80-119,472-474,501-541 and
 // GAN/multipassGAN-4x.py:505-526, GAN/multipassGAN-out.py:220-237,357 (reference tree).
 #include <mutex>
+#include <type_traits>
 
 #include "mpgan_internal.h"
 
@@ -31,6 +32,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef MPG_AH
 #define MPG_AH 2
+#endif
+// development switches of the F16F8 K loop (tools/probe_variants.py builds one library per setting):
+//   MPG_LATE_DMA 1: the second half of a block's waves (the partners of waves 0..WAVES/2-1 on the SIMDs) issue their
+//                   LDS-DMA pieces in the middle of the stage body instead of at its head
+//   MPG_PRIO 1:     static s_setprio 1 for that half
+#ifndef MPG_LATE_DMA
+#define MPG_LATE_DMA 0
+#endif
+#ifndef MPG_PRIO
+#define MPG_PRIO 0
+#endif
+//   MPG_KASM 1:     the stage body issues its LDS fragment reads as explicit ds_read_b128 in program order, MPG_AH MFMA
+//                   groups ahead of their use, and waits with counted `s_waitcnt lgkmcnt(n)` tied to the fragment
+//                   (the compiler otherwise sinks the reads next to their use and waits with lgkmcnt(0): one full LDS
+//                   round trip exposed per group)
+#ifndef MPG_KASM
+#define MPG_KASM 1
+#endif
+//   MPG_STAMPS 1:   diagnostic build only: every wave accumulates, over the stages of its K loop, the s_memtime cycles
+//                   spent (0) from the barrier release to the end of its DMA issue, (1) in the fp16 groups, (2) in the
+//                   fp8 groups, (3) waiting at the `s_waitcnt vmcnt / s_barrier` of the next stage, and writes the four
+//                   sums to y[(block * WAVES + wave) * 4 ..] when desc.reserved has bit 3 set (tools/probe_stamps.py)
+#ifndef MPG_STAMPS
+#define MPG_STAMPS 0
 #endif
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
@@ -423,13 +448,63 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 // `s_waitcnt vmcnt(0)` in front of it while LDS-DMA pieces are in flight (it cannot tell the read from the DMA's
 // destination), which serialises every stage behind its own weight / image DMAs; ext_vector_type reads do not.
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 
 // 32 bytes of LDS as two 16-byte reads: a single v8i (32-byte) read is split by the compiler into two ds_read_b128
 // that again carry the conservative `s_waitcnt vmcnt(0)` against pending LDS-DMA
+// The two halves of a lane's 32 bytes sit 1 KiB apart ([half][lane][16 B]): consecutive lanes read consecutive
+// 16-byte words, which ds_read_b128 serves without bank conflicts (a [lane][32 B] layout is 2-way conflicted).
 __device__ __forceinline__ v8i lds_read32(const char* p) {
     const v4i lo = *reinterpret_cast<const v4i*>(p);
-    const v4i hi = *reinterpret_cast<const v4i*>(p + 16);
+    const v4i hi = *reinterpret_cast<const v4i*>(p + 1024);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ---- explicit LDS reads / counted waits (MPG_KASM) ----
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int OFF, class T>
+__device__ __forceinline__ void ds_read16(T& dst, unsigned addr) {
+    static_assert(sizeof(T) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int OFF, class T>
+__device__ __forceinline__ void ds_read8(T& dst, unsigned addr) {
+    static_assert(sizeof(T) == 8 && OFF >= 0 && OFF < 65536, "one ds_read_b64");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// wait until at most N of the LDS reads issued so far are outstanding (they return in order); tying the wait to the
+// fragment keeps every instruction that consumes it behind the wait
+template <int N, class T>
+__device__ __forceinline__ void lgkm_wait(T& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N < 15 ? N : 15));
+}
+
+// bookkeeping of the explicit schedule (all compile-time): fp16 group h = (k-step h / NT, cout tile h % NT) issues
+// [PT B fragments when h % NT == 0] + 1 A fragment; the fp8 operands ride behind the last four groups
+constexpr int kx_cum(int h, int NT, int PT) { return h + PT * ((h + NT - 1) / NT); }
+constexpr int kx_extra(int g, int NT, int PT) {
+    const int G16 = 4 * NT;
+    if (g < G16 - 4) return 0;
+    int e = 2 * PT * (g - (G16 - 4) + 1);
+    if (g >= G16 - 2) e += 4;
+    if (g >= G16 - 1 && NT > 1) e += 4;
+    return e;
+}
+// reads that may still be outstanding when group g's MFMAs start: everything issued after group g's own fragments
+constexpr int kx_allowed(int g, int NT, int PT, int AH) {
+    const int G16 = 4 * NT;
+    const int hi = g + AH + 1 < G16 ? g + AH + 1 : G16;
+    const int e0 = g - AH - 1;
+    return (kx_cum(hi, NT, PT) - kx_cum(g + 1, NT, PT)) + (kx_extra(g, NT, PT) - (e0 >= 0 ? kx_extra(e0, NT, PT) : 0));
 }
 
 template <int NT>
@@ -486,6 +561,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 
     const int sa_hi = (127 - SA_HI) * 0x01010101;
     const int sa_lo = (127 - SA_LO) * 0x01010101;
+    const bool late = MPG_LATE_DMA && wave_u >= WAVES / 2;      // wave-uniform
+    if (MPG_PRIO && wave_u >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
     // The K segments are independent partial sums.  Blocks that share a CU (workgroups go round-robin over the 8
     // XCDs, then over the 32 CUs of an XCD: co-resident blocks differ in bit 8 of the id) walk them in opposite
@@ -564,8 +641,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const v8i w8_hi = lds_read32(wb + WF16 + (nt * 64 + lane) * 32);
-                    const v8i w8_lo = lds_read32(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+                    const v8i w8_hi = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
+                    const v8i w8_lo = lds_read32(wb + WF16 + WF8 + nt * 2048 + lane * 16);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
                         acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
@@ -636,16 +713,72 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             for (int i = 0; i < NI; ++i) dma16(src + i * (THREADS * 16), dst + i * (THREADS * 16));
         };
 
+#if MPG_KASM
+        // Every group's image has the same per-lane source offsets (only the group's base address differs): they are
+        // worked out once per segment, so that inside the stage loop an image piece costs a select and one DMA
+        // instruction.  -1: the pixel lies outside the image (or past the halo rows): it is fetched from the zero page.
+        constexpr int MAXI = (WAVES == 8) ? 4 : 7;       // pieces per wave and image: 2 planes x <= 14 KiB over WAVES waves
+        int img_src[MAXI];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int pc = WAVES * i + wave_u;
+            const int pl = pc / ppg;
+            const int p = (pc - pl * ppg) * 64 + lane;
+            const int hy = p / sg.iw;
+            const int hx = p - hy * sg.iw;
+            const int yy = y0 - sg.pt + hy;
+            const int xx = x0 - sg.pl + hx;
+            const bool ok = pl < 2 && hy < sg.ih && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+            img_src[i] = ok ? (int)(((size_t)pl * plane_px + (size_t)(yy >> sg.up) * sg.ws + (xx >> sg.up)) * 16) : -1;
+        }
+        const size_t group_bytes = 2 * plane_px * 16;
+        const char* const x_first = sg.x + ((size_t)n * sg.cg_total + sg.g_off) * group_bytes;   // uniform
+        // piece i (compile-time) of the image of channel group `chunk` (uniform)
+        auto img_piece = [&](int chunk, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if (i < sg.ni_img) {
+                const int off = img_src[i];
+                const char* src = (off >= 0 && chunk < sg.cg_seg) ? x_first + (size_t)chunk * group_bytes + off : a.zeros;
+                dma16_stream(src, img_lds + (chunk & 1) * a.img_bytes + (WAVES * i + wave_u) * 1024);
+            }
+        };
+        auto w_piece = [&](int stage, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int sidx = stage < NS ? stage : NS - 1;
+            dma16(sg.w + (size_t)sidx * WSTAGE + tid * 16 + i * (THREADS * 16),
+                  w_lds + (stage % R) * WSTAGE + wave_u * 1024 + i * (THREADS * 16));
+        };
+        static_for<0, MAXI>([&](auto ic) { img_piece(0, ic); });
+#else
         dma_image(0);
+#endif
 #pragma unroll
         for (int d = 0; d < D; ++d) dma_stage(d);
         int g_next = 1;                                  // next group image to fetch
         const char* img = img_lds;
+#if MPG_STAMPS
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts3_prev = 0;
+        unsigned sum_dma = 0, sum_f16 = 0, sum_f8 = 0, sum_bar = 0;
+#define MPG_STAMP(v) asm volatile("s_memtime %0" : "=s"(v))
+#else
+#define MPG_STAMP(v)
+#endif
 
         for (int st = 0; st < NS; ++st) {
             // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
             // with stage st-1
             wait_dma_and_barrier<(D - 1) * NI>();
+#if MPG_STAMPS
+            // the barrier's lgkmcnt(0) completed every stamp of the previous stage
+            if (st > 0) {
+                sum_dma += (unsigned)(ts1 - ts0);
+                sum_f16 += (unsigned)(ts2 - ts1);
+                sum_f8 += (unsigned)(ts3 - ts2);
+                if (st > 1) sum_bar += (unsigned)(ts0 - ts3_prev);
+                ts3_prev = ts3;
+            }
+            MPG_STAMP(ts0);
+#endif
             // tap offsets of the whole stage in two 16-byte reads, before this stage's DMAs are issued (the compiler
             // orders LDS reads behind pending LDS-DMA writes)
             const v4i o16 = *reinterpret_cast<const v4i*>(tap16 + (st * 2 + hh) * 4);
@@ -653,14 +786,132 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             asm volatile("" ::"v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w), "v"(o8.x), "v"(o8.y), "v"(o8.z), "v"(o8.w));
             // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
             // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
-            if (g_next < G && st * 8 >= (g_next - 1) * sg.tp) {
-                dma_image(g_next);
-                ++g_next;
-            }
-            dma_stage(st + D);
+            auto issue_dma = [&]() {
+                if (g_next < G && st * 8 >= (g_next - 1) * sg.tp) {
+                    dma_image(g_next);
+                    ++g_next;
+                }
+                dma_stage(st + D);
+            };
+#if MPG_KASM
+            // The LDS-DMA pieces of this stage are spread over its MFMA groups (one piece at a time between the MFMAs)
+            // instead of being issued as a burst behind the barrier: a burst of WAVES x (NI + image pieces) 1-KiB
+            // pieces queues up in the CU's address unit for ~1000-1500 cycles in which no wave issues an MFMA
+            // (measured with MPG_STAMPS).  Order within the stage: the image pieces in the first half of the groups,
+            // then the NI weight pieces of stage st + D, so `vmcnt((D-1) NI)` at the next barrier still covers them.
+            const bool do_img = g_next < G && st * 8 >= (g_next - 1) * sg.tp;
+            const int img_chunk = g_next;
+            if (do_img) ++g_next;
+#else
+            if (!late) issue_dma();
+#endif
+            MPG_STAMP(ts1);
             const char* wb = w_lds + (st % R) * WSTAGE;
             const int to16[4] = {o16.x, o16.y, o16.z, o16.w};
             const int to8[4] = {o8.x, o8.y, o8.z, o8.w};
+#if MPG_KASM
+            {
+                constexpr int AH = MPG_AH, G16 = 4 * NT;
+                constexpr int NB = (AH + NT - 1) / NT + 1;     // k-steps of B fragments alive: the current one + the look-ahead
+                half8 aq[AH + 1], bq[NB][PT];
+                v2i b8h[PT][4], b8l[PT][4];                      // fp8 B operands: taps 4 hh + i, {hi8 | lo8} of 8 channels each
+                v4i wq[2][2][2];                                 // [buffer][plane hi / lo][half of the lane's 32 bytes]
+                const unsigned a_base = lds_off(wb) + (unsigned)lane * 16u;
+                const unsigned i_base = lds_off(img);
+                unsigned b_addr[4][PT], b8_addr[4][PT];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        b_addr[j][pt] = i_base + (unsigned)(pixb[pt] + to16[j]);
+                        b8_addr[j][pt] = i_base + (unsigned)(plane_b + pixb[pt] + to8[j]);
+                    }
+                auto read_group = [&](auto gc) {
+                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
+                    if constexpr (nt == 0)
+                        static_for<0, PT>([&](auto pc) {
+                            constexpr int pt = decltype(pc)::value;
+                            ds_read16<0>(bq[j % NB][pt], b_addr[j][pt]);
+                        });
+                    ds_read16<(j * NT + nt) * 1024>(aq[g % (AH + 1)], a_base);
+                };
+                auto read_w8 = [&](auto nc) {
+                    constexpr int nt = decltype(nc)::value;
+                    ds_read16<WF16 + nt * 2048>(wq[nt & 1][0][0], a_base);
+                    ds_read16<WF16 + nt * 2048 + 1024>(wq[nt & 1][0][1], a_base);
+                    ds_read16<WF16 + WF8 + nt * 2048>(wq[nt & 1][1][0], a_base);
+                    ds_read16<WF16 + WF8 + nt * 2048 + 1024>(wq[nt & 1][1][1], a_base);
+                };
+                auto read_b8 = [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        ds_read8<0>(b8h[pt][i], b8_addr[i][pt]);
+                        ds_read8<8>(b8l[pt][i], b8_addr[i][pt]);
+                    });
+                };
+                static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
+                constexpr int HALF = G16 / 2;
+                constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
+                constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
+                static_for<0, G16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
+                    if constexpr (g < HALF) {
+                        if (do_img)
+                            static_for<0, IPG>([&](auto kc) {
+                                constexpr int i = g * IPG + decltype(kc)::value;
+                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
+                            });
+                    } else {
+                        static_for<0, WPG>([&](auto kc) {
+                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
+                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
+                        });
+                    }
+                    if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
+                    // the correction operands ride behind the last fp16 groups
+                    if constexpr (g >= G16 - 4) read_b8(std::integral_constant<int, g - (G16 - 4)>{});
+                    if constexpr (g == G16 - 2) read_w8(std::integral_constant<int, 0>{});
+                    if constexpr (g == G16 - 1 && NT > 1) read_w8(std::integral_constant<int, 1>{});
+                    constexpr int N = kx_allowed(g, NT, PT, AH);
+                    lgkm_wait<N>(aq[g % (AH + 1)]);
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        lgkm_wait<N>(bq[j % NB][pt]);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bq[j % NB][pt], acc[pt][nt], 0, 0, 0);
+                    });
+                });
+                MPG_STAMP(ts2);
+                static_for<0, NT>([&](auto nc) {
+                    constexpr int nt = decltype(nc)::value;
+                    constexpr int N8 = (nt + 1 < NT) ? 4 : 0;     // only the next cout tile's weight planes may be in flight
+                    static_for<0, 2>([&](auto hc) {
+                        lgkm_wait<N8>(wq[nt & 1][0][decltype(hc)::value]);
+                        lgkm_wait<N8>(wq[nt & 1][1][decltype(hc)::value]);
+                    });
+                    const v8i w_hi = __builtin_shufflevector(wq[nt & 1][0][0], wq[nt & 1][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    const v8i w_lo = __builtin_shufflevector(wq[nt & 1][1][0], wq[nt & 1][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        if constexpr (nt == 0)
+                            static_for<0, 4>([&](auto ic) {
+                                lgkm_wait<N8>(b8h[pt][decltype(ic)::value]);
+                                lgkm_wait<N8>(b8l[pt][decltype(ic)::value]);
+                            });
+                        const v4i h01 = __builtin_shufflevector(b8h[pt][0], b8h[pt][1], 0, 1, 2, 3);
+                        const v4i h23 = __builtin_shufflevector(b8h[pt][2], b8h[pt][3], 0, 1, 2, 3);
+                        const v4i l01 = __builtin_shufflevector(b8l[pt][0], b8l[pt][1], 0, 1, 2, 3);
+                        const v4i l23 = __builtin_shufflevector(b8l[pt][2], b8l[pt][3], 0, 1, 2, 3);
+                        const v8i bh = __builtin_shufflevector(h01, h23, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const v8i bl = __builtin_shufflevector(l01, l23, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_hi, bl, acc[pt][nt], 0, 0, 0, sw_hi_v, 0, sa_lo);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_lo, bh, acc[pt][nt], 0, 0, 0, sw_lo_v, 0, sa_hi);
+                    });
+                    if constexpr (nt + 2 < NT) read_w8(std::integral_constant<int, nt + 2>{});
+                });
+                MPG_STAMP(ts3);
+            }
+#else
             {
                 // software-pipelined by hand: every fragment is read from LDS two MFMA groups (one group = the PT
                 // MFMAs of one weight fragment) before the group that consumes it
@@ -677,8 +928,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                     aq[g % (AH + 1)] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
                 };
                 auto read_w8 = [&](int nt) {
-                    wq[nt & 1][0] = lds_read32(wb + WF16 + (nt * 64 + lane) * 32);
-                    wq[nt & 1][1] = lds_read32(wb + WF16 + WF8 + (nt * 64 + lane) * 32);
+                    wq[nt & 1][0] = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
+                    wq[nt & 1][1] = lds_read32(wb + WF16 + WF8 + nt * 2048 + lane * 16);
                 };
                 auto read_b8 = [&](int i) {
 #pragma unroll
@@ -692,6 +943,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 for (int g = 0; g < AH; ++g) read_group(g);
 #pragma unroll
                 for (int g = 0; g < 4 * NT; ++g) {
+                    if (MPG_LATE_DMA && g == 2 * NT && late) issue_dma();
                     if (g + AH < 4 * NT) read_group(g + AH);
                     // the correction operands ride behind the last fp16 groups
                     if (g >= 4 * NT - 4) read_b8(g - (4 * NT - 4));
@@ -714,15 +966,22 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                     if (nt + 2 < NT) read_w8(nt + 2);
                 }
             }
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if MPG_STAMPS
+        if ((a.dbg & 8) && a.y != nullptr && s == 0 && lane == 0) {
+            unsigned* o = reinterpret_cast<unsigned*>(a.y) + ((size_t)blockIdx.x * WAVES + wave) * 4;
+            o[0] = sum_dma; o[1] = sum_f16; o[2] = sum_f8; o[3] = sum_bar;
+        }
+#endif
     }
     conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
 }
 
 // F16F8 weight image: per stage (8 consecutive tap slots of the segment's slot stream; fold: 8 channel groups):
-//   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][64 lanes][32 x fp8 hi]  |  [NT][64 lanes][32 x fp8 lo]
+//   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][2 halves][64 lanes][16 x fp8 hi]  |  [NT][2 halves][64 lanes][16 x fp8 lo]
 __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                        int cin, int cout, float wscale, const float* __restrict__ cscale,
                                        int NT, int nchunks, int sc, float s_hi, float s_lo, int fold, int tp,
@@ -771,8 +1030,10 @@ __global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int 
         const int phi = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v * s_hi, -lim), lim), 0.f, 0, false) & 0xff;
         const int plo = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(lo * s_lo, -lim), lim), 0.f, 0, false) & 0xff;
         char* f8 = base + 4 * NT * 1024;
-        f8[((size_t)nt * 64 + lane) * 32 + bb] = (char)phi;
-        f8[(size_t)NT * 2048 + ((size_t)nt * 64 + lane) * 32 + bb] = (char)plo;
+        // per cout tile: [half of the lane's 32 bytes][lane][16 B] (see lds_read32)
+        const size_t at = (size_t)nt * 2048 + (size_t)(bb >> 4) * 1024 + (size_t)lane * 16 + (bb & 15);
+        f8[at] = (char)phi;
+        f8[(size_t)NT * 2048 + at] = (char)plo;
     }
 }
 

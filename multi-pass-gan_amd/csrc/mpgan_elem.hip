@@ -312,6 +312,61 @@ __global__ void cutoff_kernel(const float* __restrict__ v, size_t n, float cutof
     out[idx] = x < cutoff ? 0.f : x;
 }
 
+
+// tf.nn.conv2d_transpose(x, W[kh,kw,cout,cin], output_shape [n, h*sh, w*sw, cout], strides, "SAME") (GAN.py:703-708):
+// the gradient of the SAME convolution that maps the OUTPUT grid to the input grid, written as a gather.  Forward
+// geometry on the output grid: out = ceil(H/s), pad_total = max((out-1) s + k - H, 0), pad_before = pad_total / 2;
+// y[oy] = sum over (iy, ky) with iy*s + ky - pad_before == oy of x[iy] * W[ky].  One thread per output element,
+// cout fastest: the lanes of a pixel share the x reads (broadcast), W rows are contiguous over cin.
+__global__ void conv_transpose_kernel(const float* __restrict__ x, int n, int h, int w, int cin,
+                                      const float* __restrict__ wt, int kh, int kw, int cout, int sh, int sw,
+                                      int pad_t, int pad_l, float wscale, const float* __restrict__ bias, int act,
+                                      float leak, float* __restrict__ y) {
+    const int oh = h * sh, ow = w * sw;
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * cout;
+    if (idx >= total) return;
+    const int co = idx % cout;
+    size_t p = idx / cout;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    float acc = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+        const int ty = oy + pad_t - ky;
+        if (ty < 0 || ty % sh) continue;
+        const int iy = ty / sh;
+        if (iy >= h) continue;
+        for (int kx = 0; kx < kw; ++kx) {
+            const int tx = ox + pad_l - kx;
+            if (tx < 0 || tx % sw) continue;
+            const int ix = tx / sw;
+            if (ix >= w) continue;
+            const float* xr = x + (((size_t)b * h + iy) * w + ix) * cin;
+            const float* wr = wt + (((size_t)ky * kw + kx) * cout + co) * cin;
+            for (int ci = 0; ci < cin; ++ci) acc = fmaf(xr[ci], wr[ci], acc);
+        }
+    }
+    acc = acc * wscale + (bias != nullptr ? bias[co] : 0.f);
+    y[idx] = mpg::apply_act(acc, act, leak);
+}
+
+// tf.depth_to_space(x, r) (GAN.pixel_shuffle, GAN.py:554-560): y[b, r*q + i, r*p + j, c] = x[b, q, p, (i*r + j)*C + c]
+__global__ void depth_to_space_kernel(const float* __restrict__ x, int n, int h, int w, int c_out, int r,
+                                      float* __restrict__ y) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const int oh = h * r, ow = w * r;
+    const size_t total = (size_t)n * oh * ow * c_out;
+    if (idx >= total) return;
+    const int c = idx % c_out;
+    size_t p = idx / c_out;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const int q = oy / r, i = oy - q * r, pp = ox / r, j = ox - pp * r;
+    y[idx] = x[(((size_t)b * h + q) * w + pp) * ((size_t)c_out * r * r) + (size_t)(i * r + j) * c_out + c];
+}
+
 }  // namespace
 
 extern "C" int mpg_conv2d_direct(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
@@ -468,4 +523,28 @@ extern "C" int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float c
     if (n == 0) return MPG_OK;
     hipLaunchKernelGGL(cutoff_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, v, n, cutoff, out);
     MPG_LAUNCH_CHECK("cutoff_kernel");
+}
+
+extern "C" int mpg_conv2d_transpose(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* w_hwoi,
+                                    int kh, int kw, int cout, int stride_h, int stride_w, float wscale, const float* bias,
+                                    int act, float leak, float* y) {
+    MPG_REQUIRE(x && w_hwoi && y, "mpg_conv2d_transpose: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1 && kh >= 1 && kw >= 1 && stride_h >= 1 && stride_w >= 1,
+                "mpg_conv2d_transpose: bad shape");
+    MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_conv2d_transpose: bad activation %d", act);
+    const int pad_h = kh - stride_h > 0 ? kh - stride_h : 0, pad_w = kw - stride_w > 0 ? kw - stride_w : 0;
+    const size_t total = (size_t)n * h * stride_h * w * stride_w * cout;
+    hipLaunchKernelGGL(conv_transpose_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, cin, w_hwoi,
+                       kh, kw, cout, stride_h, stride_w, pad_h / 2, pad_w / 2, wscale, bias, act, leak, y);
+    MPG_LAUNCH_CHECK("conv_transpose_kernel");
+}
+
+extern "C" int mpg_depth_to_space(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int r, float* y) {
+    MPG_REQUIRE(x && y, "mpg_depth_to_space: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && r >= 1 && c >= r * r && c % (r * r) == 0,
+                "mpg_depth_to_space: %d channels are not a multiple of %d^2", c, r);
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(depth_to_space_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, c / (r * r),
+                       r, y);
+    MPG_LAUNCH_CHECK("depth_to_space_kernel");
 }

@@ -266,6 +266,24 @@ def conv2d(x, w, stride, wscale):
     return Node("conv2d", [x, w], shape=(x.shape[0], oh, ow, cout), stride=(sh, sw), wscale=float(wscale))
 
 
+def conv2d_transpose(x, w, stride, wscale):
+    """tf.nn.conv2d_transpose(x, W * wscale, [N, H*sh, W*sw, Cout], strides, SAME) with W[kh,kw,Cout,Cin] (GAN.py:703-708)"""
+    kh, kw, cout, cin = w.shape
+    if x.shape[3] != cin:
+        raise GraphError("conv2d_transpose: input has %s channels, weights expect %d" % (x.shape[3], cin))
+    sh, sw = stride
+    return Node("conv2d_transpose", [x, w], shape=(x.shape[0], x.shape[1] * sh, x.shape[2] * sw, cout), stride=(sh, sw),
+                wscale=float(wscale))
+
+
+def depth_to_space(x, r):
+    """tf.depth_to_space (GAN.py:559)"""
+    r = int(r)
+    if x.shape[3] % (r * r):
+        raise GraphError("depth_to_space: %s channels, block size %d" % (x.shape[3], r))
+    return Node("depth_to_space", [x], shape=(x.shape[0], x.shape[1] * r, x.shape[2] * r, x.shape[3] // (r * r)), r=r)
+
+
 def bias_add(x, b):
     return Node("bias_add", [x, b], shape=x.shape)
 

@@ -261,6 +261,79 @@ def conv2d_direct(x, w_hwio, stride=(1, 1), wscale=1.0, cout_scale=None, bias=No
     return y
 
 
+def depth_to_space(x, r):
+    """tf.depth_to_space (GAN.pixel_shuffle, GAN.py:554-560): [N,H,W,C] -> [N,H*r,W*r,C/r^2]"""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    if c % (r * r):
+        raise _lib.MpgError("depth_to_space: %d channels are not a multiple of %d^2" % (c, r))
+    y = torch.empty((n, h * r, w * r, c // (r * r)), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_depth_to_space(_stream(), _ptr(x), n, h, w, c, r, _ptr(y)), "mpg_depth_to_space")
+    return y
+
+
+def subpixel_filter(w_hwoi, stride):
+    """The stride-s transposed convolution as ONE stride-1 SAME convolution with s*s*cout outputs followed by
+    depth_to_space: output row s*q + p gathers x[q + e] * W[ky] for the taps ky with (p + pad - ky) = s*e, so each
+    output phase p is a stride-1 correlation over the offsets e.  Returns V[K',K',cin,s*s*cout] (K' odd) in HWIO."""
+    kh, kw, cout, cin = w_hwoi.shape
+    s = int(stride)
+    pad = [max(k - s, 0) // 2 for k in (kh, kw)]
+
+    def taps(k, p0):
+        out = []            # (phase, tap, offset e)
+        for ph in range(s):
+            for t in range(k):
+                if (ph + p0 - t) % s == 0:
+                    out.append((ph, t, (ph + p0 - t) // s))
+        return out
+
+    ty, tx = taps(kh, pad[0]), taps(kw, pad[1])
+    ey = max([abs(e) for _, _, e in ty] + [0])
+    ex = max([abs(e) for _, _, e in tx] + [0])
+    v = torch.zeros((2 * ey + 1, 2 * ex + 1, cin, s * s * cout), dtype=w_hwoi.dtype, device=w_hwoi.device)
+    for py, ky, dy in ty:
+        for px, kx, dx in tx:
+            c0 = (py * s + px) * cout
+            v[ey + dy, ex + dx, :, c0:c0 + cout] = w_hwoi[ky, kx].t()
+    return v
+
+
+def conv2d_transpose(x, w_hwoi, stride=(1, 1), wscale=1.0, bias=None, act=None, leak=0.2, prec=None):
+    """tf.nn.conv2d_transpose(x, W[kh,kw,cout,cin], [N, H*sh, W*sw, cout], strides, "SAME") + bias + act
+    (GAN.deconvolutional_layer, GAN.py:566-619,703-708).  prec None: the fp32 vector-ALU kernel (any stride / filter).
+    prec 1/2/3: the matrix cores -- stride 1 as the fused convolution with the mirrored filter, stride 2 as a fused
+    convolution with the sub-pixel filter + depth_to_space; shapes that route cannot take fall back to the fp32 kernel."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    w = _dev(w_hwoi, "w_hwoi")
+    n, h, wd, cin = x.shape
+    kh, kw, cout, cin2 = w.shape
+    if cin != cin2:
+        raise _lib.MpgError("conv2d_transpose: input has %d channels, filter expects %d" % (cin, cin2))
+    sh, sw = stride
+    b = _dev(bias, "bias") if bias is not None else None
+    if prec is not None and sh == sw and sh in (1, 2):
+        if sh == 1 and kh <= 7 and kw <= 7 and cout <= 128:
+            v = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()
+            p = prec if f8_available(cout, [(kh, kw, cin)]) or prec != PREC_F16F8 else PREC_F16X3
+            seg = Segment(x, pack_conv_weights(v, wscale=wscale, prec=p), pad_hi=1)
+            return conv2d_fused([seg], (h, wd), bias=b, act=act, leak=leak)
+        if sh == 2 and 4 * cout <= 128:
+            v = subpixel_filter(w, 2)
+            if v.shape[0] <= 7 and v.shape[1] <= 7:
+                p = prec if f8_available(4 * cout, [(v.shape[0], v.shape[1], cin)]) or prec != PREC_F16F8 else PREC_F16X3
+                seg = Segment(x, pack_conv_weights(v, wscale=wscale, prec=p))
+                z = conv2d_fused([seg], (h, wd), bias=b.repeat(4) if b is not None else None, act=act, leak=leak)
+                return depth_to_space(z, 2)
+    y = torch.empty((n, h * sh, wd * sw, cout), dtype=torch.float32, device=x.device)
+    rc = lib.mpg_conv2d_transpose(_stream(), _ptr(x), n, h, wd, cin, _ptr(w), kh, kw, cout, sh, sw, float(wscale), _ptr(b),
+                                  _lib.act_id(act), leak, _ptr(y))
+    _lib.check(rc, "mpg_conv2d_transpose")
+    return y
+
+
 def _resize(fn_name, x, oh, ow):
     lib = _lib.load()
     x = _dev(x, "x")

@@ -545,7 +545,10 @@ class Session(object):
                 return train_ops.lerp(xin, self._f32(env, n.inputs[-1]), tv)
 
             return list(n.inputs), run_lerp
-        if op in ("conv2d", "bias_add", "batch_norm"):
+        if op == "depth_to_space":
+            x = n.inputs[0]
+            return [x], lambda env: ops.depth_to_space(self._f32(env, x), n.attrs["r"])
+        if op in ("conv2d", "conv2d_transpose", "bias_add", "batch_norm"):
             direct = self._match_direct(n, single_use)
             if direct is not None:
                 return direct
@@ -574,7 +577,7 @@ class Session(object):
             if not single_use(cur.inputs[0]):
                 return None
             cur = cur.inputs[0]
-        if cur.op not in ("conv2d", "matmul"):
+        if cur.op not in ("conv2d", "matmul", "conv2d_transpose"):
             return None
         conv = cur
         x, wv = conv.inputs
@@ -586,6 +589,10 @@ class Session(object):
             b = eff.float().contiguous()
             w = self.vars.get(wv.attrs["var"])
             xin = self._f32(env, x)
+            if conv.op == "conv2d_transpose":
+                # GAN.deconvolutional_layer: batch norm folds into the filter's output-channel axis (axis 2 of [kh,kw,cout,cin])
+                wf = w if scale is None else (w * scale.view(1, 1, -1, 1)).contiguous()
+                return ops.conv2d_transpose(xin, wf, conv.attrs["stride"], conv.attrs["wscale"], b, act, leak, prec=self.prec)
             if is_fc and scale is None:
                 from . import train_ops
                 return train_ops.fc_forward(xin.contiguous(), w, conv.attrs["wscale"], b, act, leak)

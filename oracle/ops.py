@@ -48,6 +48,32 @@ def conv2d_same(x, w, stride=(1, 1)):
     return out.astype(F32)
 
 
+def conv2d_transpose_same(x, w, stride=(1, 1)):
+    """``tf.nn.conv2d_transpose(x, W, output_shape=[N, H*sh, W*sw, Cout], strides, "SAME")`` (GAN.py:703-708).
+
+    x: [N,H,W,Cin]; w: [kh,kw,Cout,Cin] (TensorFlow's transposed-filter layout).  Written from the definition -- the
+    gradient of ``conv2d_same`` on the OUTPUT grid: every input pixel scatters x * W into the padded output, the SAME
+    padding of the forward convolution (``same_pad`` on the output size) is cropped.  float64 accumulation."""
+    x = np.asarray(x)
+    w = np.asarray(w)
+    n, h, wd, cin = x.shape
+    kh, kw, cout, cin2 = w.shape
+    assert cin == cin2, (x.shape, w.shape)
+    sh, sw = stride
+    oh, ow = h * sh, wd * sw
+    fo_h, pt, _ = same_pad(oh, kh, sh)
+    fo_w, pl, _ = same_pad(ow, kw, sw)
+    assert (fo_h, fo_w) == (h, wd)
+    full = np.zeros((n, (h - 1) * sh + kh + sh, (wd - 1) * sw + kw + sw, cout), dtype=np.float64)
+    w64 = w.astype(np.float64)
+    x64 = x.astype(np.float64)
+    for ky in range(kh):
+        for kx in range(kw):
+            contrib = x64.reshape(-1, cin).dot(w64[ky, kx].T).reshape(n, h, wd, cout)
+            full[:, ky:ky + (h - 1) * sh + 1:sh, kx:kx + (wd - 1) * sw + 1:sw, :] += contrib
+    return full[:, pt:pt + oh, pl:pl + ow, :].astype(F32)
+
+
 def wscale(shape, gain=math.sqrt(2.0)):
     """Equalised-LR constant of ``GAN.weight_variable`` (GAN.py:661-668):
     float32(gain / sqrt(prod(shape[:-1])))."""

@@ -97,8 +97,13 @@ def test_gan_layer_side_effects(mpg):
     assert gan.y().shape == (None, 1)
     assert gan.getDOFs() == 3 * 3 * 3 * 16 + 16 + 16 * 4 + 4 + n + 1
     assert list(G.get_default_graph().variables) == ["c1/weight", "c1/bias", "c2/weight", "c2/bias", "fc/weight", "fc/bias"]
-    with pytest.raises(TypeError):
-        gan.deconvolutional_layer(4, [2, 2])           # unusable in the reference as well (GAN.py:584)
+    gan2 = GAN(G.placeholder([None, 8, 8, 3]))
+    d, dlin = gan2.deconvolutional_layer(5, [4, 4], lrelu, stride=[2], name="up")      # GAN.py:566-619 (TypeError in the reference)
+    assert d.shape == (None, 16, 16, 5) and dlin.op == "bias_add" and dlin.inputs[0].op == "conv2d_transpose"
+    assert G.get_default_graph().variables["up/weight"].shape == (4, 4, 5, 3)
+    gan2.pixel_shuffle(upres=2, stage="1")                                                # GAN.py:554-560
+    assert gan2.layer.shape == (None, 32, 32, 5) and gan2.layer.op == "depth_to_space"
+    assert G.get_default_graph().variables["g_cPS1/weight"].shape == (3, 3, 5, 20)
     G.reset_default_graph()
 
 

@@ -442,3 +442,75 @@ def test_empty_and_bad_arguments(gpu_ops, mpg):
     with pytest.raises(MpgError):
         gpu_ops.conv2d_fused([gpu_ops.Segment(x, pk)], (16, 16))                     # shape mismatch
     assert gpu_ops.axis_zoom_linear(_t(np.zeros((4, 4, 4, 0), np.float32)), 0, 4).shape == (16, 4, 4, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# K14: tf.nn.conv2d_transpose (GAN.deconv2d, GAN.py:703-708) and tf.depth_to_space (GAN.py:559)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,s,cin,cout", [(4, 2, 16, 8), (5, 2, 8, 32), (3, 1, 12, 20), (4, 1, 8, 8), (2, 2, 3, 5),
+                                          (1, 2, 4, 4), (5, 3, 6, 2), (3, 2, 128, 16)])
+def test_conv2d_transpose_valu(gpu_ops, k, s, cin, cout):
+    """mpg_conv2d_transpose (fp32 gather, any stride / filter, TF SAME output_shape = input * stride) + bias + act"""
+    rng = _rng(k * 7 + s)
+    x = rng.standard_normal((2, 9, 11, cin)).astype(np.float32)
+    w = rng.standard_normal((k, k, cout, cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = 0.37
+    ref = O.activation(O.bias_add(O.conv2d_transpose_same(x, w * np.float32(ws), (s, s)), b), "lrelu")
+    y = gpu_ops.conv2d_transpose(_t(x), _t(w), (s, s), ws, _t(b), "lrelu").cpu().numpy()
+    assert y.shape == (2, 9 * s, 11 * s, cout)
+    assert rel_l2(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 2e-5), (2, 3e-4)])
+@pytest.mark.parametrize("k,s,cin,cout", [(4, 2, 16, 8), (5, 2, 8, 32), (3, 1, 12, 20), (4, 1, 64, 64), (3, 2, 128, 16),
+                                          (6, 2, 8, 4)])
+def test_conv2d_transpose_mfma(gpu_ops, prec, tol, k, s, cin, cout):
+    """the matrix-core route: stride 1 = fused convolution with the mirrored filter, stride 2 = fused convolution with
+    the sub-pixel filter (4 * cout outputs) + depth_to_space"""
+    rng = _rng(k * 11 + s)
+    x = rng.standard_normal((1, 16, 32, cin)).astype(np.float32)
+    w = rng.standard_normal((k, k, cout, cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = float(np.sqrt(2.0 / (k * k * cin)))
+    ref = O.activation(O.bias_add(O.conv2d_transpose_same(x, w * np.float32(ws), (s, s)), b), "relu")
+    y = gpu_ops.conv2d_transpose(_t(x), _t(w), (s, s), ws, _t(b), "relu", prec=prec).cpu().numpy()
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < tol, rel_l2(y, ref)
+
+
+def test_depth_to_space_and_deconv_layer(gpu_ops, mpg):
+    x = _rng(3).standard_normal((2, 5, 6, 12)).astype(np.float32)
+    y = gpu_ops.depth_to_space(_t(x), 2).cpu().numpy()
+    assert np.array_equal(y, O.depth_to_space(x, 2))
+    # GAN.deconvolutional_layer + pixel_shuffle through the graph / session (batch norm folded into the filter)
+    from mpgan_amd import graph as G
+    from mpgan_amd.GAN import GAN, lrelu
+    from mpgan_amd.session import Session, VariableStore
+    from oracle import nets as ON
+    prev = G.get_default_graph()
+    g = G.reset_default_graph()
+    try:
+        xin = G.placeholder([None, 6, 6, 3])
+        gan = GAN(xin)
+        out, _ = gan.deconvolutional_layer(8, [4, 4], lrelu, stride=[2], name="up", batch_norm=True)
+        ps_out = gan.pixel_shuffle(upres=2)
+    finally:
+        G._default_graph[0] = prev
+    ps = ON.ParamSource(seed=3)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in g.variables.items()}
+    for prec, tol in ((3, 1e-4), (2, 5e-4)):
+        vs = VariableStore(DEV)
+        vs.load(params)
+        sess = Session(graph=g, variables=vs, device=DEV, prec=prec)
+        xv = _rng(5).standard_normal((2, 6, 6, 3)).astype(np.float32)
+        got, got_ps = sess.run([out, ps_out], {xin: xv})
+        w = params["up/weight"]
+        r = O.conv2d_transpose_same(xv, w * O.wscale(w.shape), (2, 2))
+        r = O.batch_norm_infer(O.bias_add(r, params["up/bias"]), params["up/gamma"], params["up/beta"],
+                               params["up/moving_mean"], params["up/moving_variance"])
+        r = O.lrelu(r)
+        assert rel_l2(got, r) < tol
+        w2 = params["g_cPS1/weight"]
+        r2 = O.depth_to_space(O.bias_add(O.conv2d_same(r, w2 * O.wscale(w2.shape)), params["g_cPS1/bias"]), 2)
+        assert got_ps.shape == (2, 24, 24, 8) and rel_l2(got_ps, r2) < 2 * tol
