@@ -276,6 +276,25 @@ int mpg_tensor_resample(mpg_stream_t stream, const float* value, const float* po
                         int clamp, float* out);
 int mpg_tensor_resample_bwd(mpg_stream_t stream, const float* dy, const float* pos, int n, int h, int w, int c,
                             int clamp, float* dvalue);
+/* GAN.advect (GAN.py:347-418): semi-Lagrangian / MacCormack advection of [n,h,w,c] fields (2D, h == w) for the
+ * temporal-coherence branch with adv_mode 1 / 2 (multipassGAN-8x.py:1199,1225).
+ *   mpg_advect_velocity: vel[n,hv,wv,cv] with channels (x, y, ..) -> out[n,h,w,2] = the (y, x) displacement the look-up
+ *     uses: legacy-bilinear resize to [h,w], times max(h/hv, w/wv), averaged with its successor along its own axis
+ *     (MAC -> cell centre, zero past the end), times dt * (+1, 0, -1)[b % 3] (:376-396); n is a multiple of 3.
+ *   mpg_semi_lagrange: out[b,i,j,:] = sum over the 2x2 cells around q = (i + 0.5, j + 0.5) - sign * vel[b,i,j] of
+ *     source * prod(1 - |q - index|), indices clamped to the grid, weights from the clamped indices (:175-204).
+ *     _bwd: gradient with respect to source (dsource is overwritten).
+ *   mpg_maccormack (one channel): the MacCormack correction forward + strength/2 (source - backward) where
+ *     flags < 0.2, clamped back to `forward` where it leaves the [min, max] of the fluid cells around the truncated
+ *     look-up position (:206-343, index clipping as written there; n <= w). */
+int mpg_advect_velocity(mpg_stream_t stream, const float* vel, int n, int hv, int wv, int cv, int h, int w, float dt,
+                        float* out);
+int mpg_semi_lagrange(mpg_stream_t stream, const float* source, const float* vel, int n, int h, int w, int c,
+                      float vel_sign, float* out);
+int mpg_semi_lagrange_bwd(mpg_stream_t stream, const float* dy, const float* vel, int n, int h, int w, int c,
+                          float vel_sign, float* dsource);
+int mpg_maccormack(mpg_stream_t stream, const float* source, const float* forward, const float* backward,
+                   const float* flags, const float* vel, int n, int h, int w, float strength, float* out);
 /* the reductions of the generator losses (multipassGAN-4x.py:754,764-765): out[0] = sum |a - b| (mode 0,
  * tf.reduce_mean(tf.abs(..)) after division by n) or sum (a - b)^2 (mode 1, 2 * tf.nn.l2_loss); b NULL = 0 */
 int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out);

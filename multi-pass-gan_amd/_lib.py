@@ -120,6 +120,10 @@ PROTOTYPES = {
     "mpg_lerp": (_I, [_P, _P, _P, _Z, _F, _P]),
     "mpg_tensor_resample": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mpg_tensor_resample_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mpg_advect_velocity": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "mpg_semi_lagrange": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "mpg_semi_lagrange_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "mpg_maccormack": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mpg_pair_reduce": (_I, [_P, _P, _P, _Z, _I, _P]),
     "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _P, _F, _F, _F]),
 }

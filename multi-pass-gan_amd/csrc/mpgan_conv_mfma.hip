@@ -764,6 +764,9 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 #define MPG_STAMP(v)
 #endif
 
+#if MPG_KASM
+        v4i o16n = {0, 0, 0, 0}, o8n = {0, 0, 0, 0};
+#endif
         for (int st = 0; st < NS; ++st) {
             // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
             // with stage st-1
@@ -781,9 +784,27 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 #endif
             // tap offsets of the whole stage in two 16-byte reads, before this stage's DMAs are issued (the compiler
             // orders LDS reads behind pending LDS-DMA writes)
+#if MPG_KASM
+            // the tap tables are constant over the segment: stage st + 1's entries are read at the head of stage st (the
+            // first LDS reads of the stage, so every counted wait below sees them as older than what it waits for) and
+            // the barrier's lgkmcnt(0) has completed them when the next stage starts
+            if (st == 0) {
+                ds_read16<0>(o16n, lds_off(tap16 + hh * 4));
+                ds_read16<0>(o8n, lds_off(tapoff + 4 * hh));
+                lgkm_wait<0>(o16n);
+                lgkm_wait<0>(o8n);
+            }
+            const v4i o16 = o16n, o8 = o8n;
+            {
+                const int sn = st + 1 < NS ? st + 1 : st;
+                ds_read16<0>(o16n, lds_off(tap16 + (sn * 2 + hh) * 4));
+                ds_read16<0>(o8n, lds_off(tapoff + sn * 8 + 4 * hh));
+            }
+#else
             const v4i o16 = *reinterpret_cast<const v4i*>(tap16 + (st * 2 + hh) * 4);
             const v4i o8 = *reinterpret_cast<const v4i*>(tapoff + st * 8 + 4 * hh);
             asm volatile("" ::"v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w), "v"(o8.x), "v"(o8.y), "v"(o8.z), "v"(o8.w));
+#endif
             // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
             // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
             auto issue_dma = [&]() {
@@ -802,6 +823,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             const bool do_img = g_next < G && st * 8 >= (g_next - 1) * sg.tp;
             const int img_chunk = g_next;
             if (do_img) ++g_next;
+            // (tried: letting these image pieces stay in flight across the next barrier when their first reader is a later
+            // stage, with a vmcnt chosen per stage: +2 % time -- the extra branch costs more than the wait it removes)
 #else
             if (!late) issue_dma();
 #endif

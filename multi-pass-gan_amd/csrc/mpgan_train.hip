@@ -465,6 +465,139 @@ int fill_geom(ConvGeom& g, int n, int h, int w, int cin, int cout, int kh, int k
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// GAN.advect (tools_wscale/GAN.py:173-418), 2D, square fields: HBM-bound gathers
+// ---------------------------------------------------------------------------------------------
+// legacy tf.image.resize_images(method 0) value of channel `ch` of vel[b] at output pixel (i, j); 0 past the grid
+__device__ __forceinline__ float adv_bilinear(const float* __restrict__ vel, int b, int hv, int wv, int cv, int ch, int i,
+                                              int j, int h, int w) {
+    if (i >= h || j >= w) return 0.f;
+    const float sy = (float)i * ((float)hv / (float)h), sx = (float)j * ((float)wv / (float)w);
+    const int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    const int y1 = min(y0 + 1, hv - 1), x1 = min(x0 + 1, wv - 1);
+    const float fy = sy - (float)y0, fx = sx - (float)x0;
+    const float* base = vel + (size_t)b * hv * wv * cv + ch;
+    const float v00 = base[((size_t)y0 * wv + x0) * cv], v01 = base[((size_t)y0 * wv + x1) * cv];
+    const float v10 = base[((size_t)y1 * wv + x0) * cv], v11 = base[((size_t)y1 * wv + x1) * cv];
+    const float top = v00 + (v01 - v00) * fx, bot = v10 + (v11 - v10) * fx;
+    return top + (bot - top) * fy;
+}
+
+// :376-396 in one pass: channels (x,y) -> (y,x), bilinear resize to [h,w], times the resolution ratio, MAC -> centre
+// (average with the successor along the component's own axis, zero past the end), times dt * (+1, 0, -1)[b % 3]
+__global__ void advect_velocity_kernel(const float* __restrict__ vel, int n, int hv, int wv, int cv, int h, int w, float dt,
+                                       float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w;
+    if (idx >= total) return;
+    const int j = idx % w;
+    const int i = (idx / w) % h;
+    const int b = idx / ((size_t)w * h);
+    const float rh = (float)h / (float)hv, rw = (float)w / (float)wv;
+    const float up = fmaxf(rh, rw);
+    const float vy = adv_bilinear(vel, b, hv, wv, cv, 1, i, j, h, w) * up;
+    const float vy_n = adv_bilinear(vel, b, hv, wv, cv, 1, i + 1, j, h, w) * up;
+    const float vx = adv_bilinear(vel, b, hv, wv, cv, 0, i, j, h, w) * up;
+    const float vx_n = adv_bilinear(vel, b, hv, wv, cv, 0, i, j + 1, h, w) * up;
+    const int ph = b % 3;
+    const float step = ph == 0 ? dt : (ph == 1 ? 0.f : -dt);
+    out[idx * 2] = 0.5f * (vy + vy_n) * step;
+    out[idx * 2 + 1] = 0.5f * (vx + vx_n) * step;
+}
+
+struct AdvCorner {
+    int y[2], x[2];
+    float wy[2], wx[2];
+};
+// :175-190: p = (i + 1, j + 1) - sign * vel; q = p - 0.5; indices floor(q), floor(q) + 1 clamped; weights 1 - |q - index|
+__device__ __forceinline__ AdvCorner adv_corners(const float* __restrict__ vel, size_t pix, int i, int j, int h, int w, float sign) {
+    AdvCorner c;
+    const float qy = ((float)i + 1.0f - sign * vel[pix * 2]) - 0.5f;
+    const float qx = ((float)j + 1.0f - sign * vel[pix * 2 + 1]) - 0.5f;
+    const int y0 = (int)floorf(qy), x0 = (int)floorf(qx);
+    c.y[0] = min(max(y0, 0), h - 1); c.y[1] = min(max(y0 + 1, 0), h - 1);
+    c.x[0] = min(max(x0, 0), w - 1); c.x[1] = min(max(x0 + 1, 0), w - 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        c.wy[k] = 1.0f - fabsf(qy - (float)c.y[k]);
+        c.wx[k] = 1.0f - fabsf(qx - (float)c.x[k]);
+    }
+    return c;
+}
+
+__global__ void semi_lagrange_kernel(const float* __restrict__ src, const float* __restrict__ vel, int n, int h, int w, int c,
+                                     float sign, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const size_t pix = idx / c;
+    const int j = pix % w;
+    const int i = (pix / w) % h;
+    const int b = pix / ((size_t)w * h);
+    const AdvCorner k = adv_corners(vel, pix, i, j, h, w, sign);
+    const float* s = src + (size_t)b * h * w * c + ch;
+    float acc = 0.f;
+    // corner order of the reference: bit 0 selects the upper index on axis 0 (y), bit 1 on axis 1 (x)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc += s[((size_t)k.y[q & 1] * w + k.x[q >> 1]) * c] * (k.wy[q & 1] * k.wx[q >> 1]);
+    out[idx] = acc;
+}
+
+__global__ void semi_lagrange_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ vel, int n, int h, int w, int c,
+                                         float sign, float* __restrict__ dsrc) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    const size_t pix = idx / c;
+    const int j = pix % w;
+    const int i = (pix / w) % h;
+    const int b = pix / ((size_t)w * h);
+    const AdvCorner k = adv_corners(vel, pix, i, j, h, w, sign);
+    float* d = dsrc + (size_t)b * h * w * c + ch;
+    const float g = dy[idx];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomicAdd(d + ((size_t)k.y[q & 1] * w + k.x[q >> 1]) * c, g * (k.wy[q & 1] * k.wx[q >> 1]));
+}
+
+// MacCormackCorrect + MacCormackClamp (:206-343), one channel: corrected = forward + strength/2 (source - backward) in
+// fluid cells (flags < 0.2); kept only if it lies inside [min, max] of source over the fluid cells among the 2x2
+// neighbourhood of the truncated look-up position, else the semi-Lagrangian value.  Index clipping as the reference
+// writes it: the first corner is clipped per axis (h-1, w-1), the other three -- batch index included -- to w-1.
+__global__ void maccormack_kernel(const float* __restrict__ src, const float* __restrict__ fwd, const float* __restrict__ bwd,
+                                  const float* __restrict__ flags, const float* __restrict__ vel, int n, int h, int w,
+                                  float strength, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * h * w;
+    if (idx >= total) return;
+    const int j = idx % w;
+    const int i = (idx / w) % h;
+    const int b = idx / ((size_t)w * h);
+    const float f = fwd[idx];
+    const float corr = flags[idx] < 0.2f ? f + strength * 0.5f * (src[idx] - bwd[idx]) : f;
+    const int cy = (int)(((float)i + 1.0f) - vel[idx * 2]), cx = (int)(((float)j + 1.0f) - vel[idx * 2 + 1]);   // truncation
+    const int i0 = min(max(cy, 0), h - 1), j0 = min(max(cx, 0), w - 1);
+    const float big = 9223372036854775807.0f;
+    float lo = big, hi = -big - 1.0f;
+    const float lo_i = lo, hi_i = hi;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int di = q & 1, dj = q >> 1;
+        int bb = b, ii = i0 + di, jj = j0 + dj;
+        if (q != 0) { bb = min(max(bb, 0), w - 1); ii = min(max(ii, 0), w - 1); jj = min(max(jj, 0), w - 1); }
+        const size_t at = ((size_t)bb * h + ii) * w + jj;
+        if (flags[at] < 0.2f) {
+            const float sv = src[at];
+            lo = fminf(lo, sv);
+            hi = fmaxf(hi, sv);
+        }
+    }
+    const bool reject = corr < lo || corr > hi || lo == lo_i || hi == hi_i;
+    out[idx] = reject ? f : corr;
+}
+
 }  // namespace
 
 #define MPG_GEOM_CHECK(NAME)                                                                                  \
@@ -661,4 +794,48 @@ extern "C" int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, f
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, p, grad, m, v, n, lr_t,
                        beta1, beta2, eps);
     MPG_LAUNCH_CHECK("adam_kernel");
+}
+
+extern "C" int mpg_advect_velocity(mpg_stream_t stream, const float* vel, int n, int hv, int wv, int cv, int h, int w, float dt,
+                                   float* out) {
+    MPG_REQUIRE(vel && out, "mpg_advect_velocity: null pointer");
+    MPG_REQUIRE(n >= 1 && hv >= 1 && wv >= 1 && cv >= 2 && h >= 1 && w >= 1, "mpg_advect_velocity: bad shape");
+    MPG_REQUIRE(n % 3 == 0, "mpg_advect_velocity: the batch (%d) must hold whole frame triples", n);
+    const size_t total = (size_t)n * h * w;
+    hipLaunchKernelGGL(advect_velocity_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, vel, n, hv, wv, cv, h, w,
+                       dt, out);
+    MPG_LAUNCH_CHECK("advect_velocity_kernel");
+}
+
+extern "C" int mpg_semi_lagrange(mpg_stream_t stream, const float* source, const float* vel, int n, int h, int w, int c,
+                                 float vel_sign, float* out) {
+    MPG_REQUIRE(source && vel && out, "mpg_semi_lagrange: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "mpg_semi_lagrange: bad shape");
+    const size_t total = (size_t)n * h * w * c;
+    hipLaunchKernelGGL(semi_lagrange_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, source, vel, n, h, w, c,
+                       vel_sign, out);
+    MPG_LAUNCH_CHECK("semi_lagrange_kernel");
+}
+
+extern "C" int mpg_semi_lagrange_bwd(mpg_stream_t stream, const float* dy, const float* vel, int n, int h, int w, int c,
+                                     float vel_sign, float* dsource) {
+    MPG_REQUIRE(dy && vel && dsource, "mpg_semi_lagrange_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1, "mpg_semi_lagrange_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)n * h * w * c;
+    hipError_t e = mpg::zero_async(dsource, total * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_semi_lagrange_bwd: zero");
+    hipLaunchKernelGGL(semi_lagrange_bwd_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, dy, vel, n, h, w, c, vel_sign, dsource);
+    MPG_LAUNCH_CHECK("semi_lagrange_bwd_kernel");
+}
+
+extern "C" int mpg_maccormack(mpg_stream_t stream, const float* source, const float* forward, const float* backward,
+                              const float* flags, const float* vel, int n, int h, int w, float strength, float* out) {
+    MPG_REQUIRE(source && forward && backward && flags && vel && out, "mpg_maccormack: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1, "mpg_maccormack: bad shape");
+    MPG_REQUIRE(n <= w, "mpg_maccormack: batch %d exceeds the field width %d (the reference clips the batch index to it)", n, w);
+    const size_t total = (size_t)n * h * w;
+    hipLaunchKernelGGL(maccormack_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, source, forward, backward,
+                       flags, vel, n, h, w, strength, out);
+    MPG_LAUNCH_CHECK("maccormack_kernel");
 }

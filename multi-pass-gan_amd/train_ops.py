@@ -185,6 +185,73 @@ def tensor_resample_bwd(dy, pos, clamp=True):
     return dv
 
 
+def advect_velocity(vel, h, w, dt):
+    """the (y, x) displacement field GAN.advect looks up with (GAN.py:376-396): vel [n,hv,wv,>=2] (x,y,..) -> [n,h,w,2]"""
+    lib = _lib.load()
+    vel = _cont(vel, "vel")
+    n, hv, wv, cv = vel.shape
+    out = torch.empty((n, h, w, 2), dtype=torch.float32, device=vel.device)
+    _lib.check(lib.mpg_advect_velocity(_stream(), _ptr(vel), n, hv, wv, cv, h, w, float(dt), _ptr(out)), "mpg_advect_velocity")
+    return out
+
+
+def semi_lagrange(source, vel_c, sign=1.0):
+    lib = _lib.load()
+    source, vel_c = _cont(source, "source"), _cont(vel_c, "vel")
+    n, h, w, c = source.shape
+    if tuple(vel_c.shape) != (n, h, w, 2):
+        raise _lib.MpgError("semi_lagrange: displacement field %s does not match source %s" % (tuple(vel_c.shape), tuple(source.shape)))
+    out = torch.empty_like(source)
+    _lib.check(lib.mpg_semi_lagrange(_stream(), _ptr(source), _ptr(vel_c), n, h, w, c, float(sign), _ptr(out)), "mpg_semi_lagrange")
+    return out
+
+
+def semi_lagrange_bwd(dy, vel_c, sign=1.0):
+    lib = _lib.load()
+    dy, vel_c = _cont(dy, "dy"), _cont(vel_c, "vel")
+    n, h, w, c = dy.shape
+    ds = torch.empty_like(dy)
+    _lib.check(lib.mpg_semi_lagrange_bwd(_stream(), _ptr(dy), _ptr(vel_c), n, h, w, c, float(sign), _ptr(ds)), "mpg_semi_lagrange_bwd")
+    return ds
+
+
+class _SemiLagrangeFn(torch.autograd.Function):
+    """differentiable in `source` (a fixed linear gather): what the generator loss needs of GAN.advect with order 1"""
+
+    @staticmethod
+    def forward(ctx, source, vel_c, sign):
+        ctx.save_for_backward(vel_c)
+        ctx.sign = sign
+        return semi_lagrange(source, vel_c, sign)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (vel_c,) = ctx.saved_tensors
+        return semi_lagrange_bwd(dy.contiguous(), vel_c, ctx.sign), None, None
+
+
+def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
+    """GAN.advect (GAN.py:347-418) on [n,h,w,c] device tensors (h == w, n a multiple of 3).  order 1: semi-Lagrangian
+    (differentiable in source); order 2: MacCormack with the reference's clamp (one channel, forward only)."""
+    n, h, w, c = source.shape
+    if h != w:
+        raise _lib.MpgError("advect: the reference's position grid is only a mesh for square fields (GAN.py:362-374)")
+    vel_c = advect_velocity(vel, h, w, dt)
+    fwd = _SemiLagrangeFn.apply(source, vel_c, 1.0)
+    if order != 2:
+        return fwd
+    if c != 1 or start_bz != n:
+        raise _lib.MpgError("advect order 2: one channel and startBz == batch size (tf.where in GAN.py:343 needs both)")
+    lib = _lib.load()
+    src, f = _cont(source.detach(), "source"), _cont(fwd.detach(), "forward")
+    bwd = semi_lagrange(f, vel_c, -1.0)
+    flags = _cont(flags.reshape(n, h, w, 1), "flags")
+    out = torch.empty_like(src)
+    _lib.check(lib.mpg_maccormack(_stream(), _ptr(src), _ptr(f), _ptr(bwd), _ptr(flags), _ptr(vel_c), n, h, w, float(strength),
+                                  _ptr(out)), "mpg_maccormack")
+    return out
+
+
 def pair_reduce(a, b, mode):
     """0-dim tensor: sum |a - b| (mode 0) or sum (a - b)^2 (mode 1)"""
     lib = _lib.load()

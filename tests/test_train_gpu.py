@@ -409,3 +409,49 @@ def test_temporal_discriminator_losses_and_gradients():
     d, g = tr.train_step(xs, ys, tempo=(xts, yts, ypos))
     assert np.isfinite(float(d)) and np.isfinite(float(g))
     assert all(not torch.equal(tr.sess.params[n].detach(), before[n]) for n in tr.opt_t.names if n not in bn_bias)
+
+
+# ---------------------------------------------------------------------------------------------
+# f4: GAN.advect (GAN.py:173-418) -- semi-Lagrangian / MacCormack gather kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("hv", [8, 16])
+def test_advect_kernels_vs_oracle(hv):
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import train_ops
+    from oracle import advect as A
+    rng = np.random.default_rng(hv)
+    n, h = 6, 16
+    src = rng.random((n, h, h, 1)).astype(np.float32)
+    vel = (rng.standard_normal((n, hv, hv, 3)) * 3.0).astype(np.float32)
+    flags = (rng.random((n, h, h, 1)) < 0.25).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    # the displacement field (bilinear resize, MAC -> centre, dt pattern)
+    v = train_ops.advect_velocity(t(vel), h, h, 0.5).cpu().numpy()
+    want_v = A.centred_velocity(vel, h, h, 0.5)
+    assert np.abs(v - want_v).max() < 1e-5
+    # semi-Lagrange: vectorised oracle and the scalar loop
+    fwd = train_ops.advect(t(src), t(vel), t(flags), 0.5, 1).cpu().numpy()
+    assert np.abs(fwd - A.advect(src, vel, flags, 0.5, 1)).max() < 2e-5
+    assert np.abs(fwd - A.semi_lagrange_loop(src, want_v, A.positions(h, h))).max() < 2e-5
+    # several channels
+    src3 = rng.random((n, h, h, 3)).astype(np.float32)
+    f3 = train_ops.advect(t(src3), t(vel), None, 0.5, 1).cpu().numpy()
+    assert np.abs(f3 - A.advect(src3, vel, None, 0.5, 1)).max() < 2e-5
+    # MacCormack with the reference's clamp
+    mc = train_ops.advect(t(src), t(vel), t(flags), 0.5, 2, 1.0, start_bz=n).cpu().numpy()
+    want = A.advect(src, vel, flags, 0.5, 2, 1.0, start_bz=n)
+    bad = np.abs(mc - want) > 2e-5
+    # a corrected value sitting exactly on its clamp bound may fall on either side in fp32 vs the oracle's float64 sums
+    assert bad.mean() < 2e-3, bad.mean()
+    # gradient of the order-1 look-up with respect to the source = the transposed gather
+    s = t(src3).requires_grad_(True)
+    out = train_ops.advect(s, t(vel), None, 0.5, 1)
+    g = torch.randn_like(out)
+    (ds,) = torch.autograd.grad(out, [s], g)
+    s2 = torch.as_tensor(src3, dtype=torch.float64)
+    basis = torch.as_tensor(A.semi_lagrange(np.ones_like(src3), want_v, A.positions(h, h)))   # column sums of the weights
+    assert abs(float((ds.cpu().double().sum())) - float((g.cpu().double() * basis.double()).sum())) < 1e-2
+    # adjoint identity <advect(x), g> = <x, advect^T(g)>
+    lhs = float((out.detach().cpu().double() * g.cpu().double()).sum())
+    rhs = float((s2 * ds.cpu().double()).sum())
+    assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), 1.0)
