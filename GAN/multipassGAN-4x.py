@@ -283,6 +283,6 @@ for layerno in range(frame_min, frame_max):
     if generateUni:
         head, _ = uniio.readUni(packedSimPath + "sim_%04d/density_low_%04d.uni" % (fromSim, layerno))
         head['dimX'] = head['dimY'] = head['dimZ'] = simSizeHigh
-        uniio.writeUni(packedSimPath + '/sim_%04d/' % fromSim + name % layerno, head, vol.cpu().numpy())
+        uniio.writeUniFromDevice(packedSimPath + '/sim_%04d/' % fromSim + name % layerno, head, vol)
     print('')
 print('Test finished, %d volumes written to %s.' % (frame_max - frame_min, packedSimPath))

@@ -138,7 +138,7 @@ def output_main():
         if gen_uni:
             head = dict(head_0)
             head['dimX'] = head['dimY'] = head['dimZ'] = s
-            uniio.writeUni(sims + '/sim_%04d/' % from_sim + out_name % layerno, head, vol.cpu().numpy())
+            uniio.writeUniFromDevice(sims + '/sim_%04d/' % from_sim + out_name % layerno, head, vol)
     print('Test finished, %d volumes written to %s.' % (f1 - f0, sims))
 
 

@@ -132,6 +132,6 @@ for layerno in range(frame_min, frame_max):
     if generateUni:
         head = dict(head_0)
         head['dimX'] = head['dimY'] = head['dimZ'] = simSizeHigh
-        uniio.writeUni(packedSimPath + '/sim_%04d/source_%04d.uni' % (fromSim, layerno), head, vol.cpu().numpy())
+        uniio.writeUniFromDevice(packedSimPath + '/sim_%04d/source_%04d.uni' % (fromSim, layerno), head, vol)
         print('stored .uni file')
 print('Test finished, %d volumes written to %s.' % (frame_max - frame_min, packedSimPath))

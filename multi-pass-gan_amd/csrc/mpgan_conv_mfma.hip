@@ -33,16 +33,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_AH
 #define MPG_AH 2
 #endif
-// development switches of the F16F8 K loop (tools/probe_variants.py builds one library per setting):
-//   MPG_LATE_DMA 1: the second half of a block's waves (the partners of waves 0..WAVES/2-1 on the SIMDs) issue their
-//                   LDS-DMA pieces in the middle of the stage body instead of at its head
-//   MPG_PRIO 1:     static s_setprio 1 for that half
-#ifndef MPG_LATE_DMA
-#define MPG_LATE_DMA 0
-#endif
-#ifndef MPG_PRIO
-#define MPG_PRIO 0
-#endif
+// development switches of the F16F8 K loop (tools/build_variants.sh builds one library per setting, tools/probe_variants.py
+// times them against each other on one box):
 //   MPG_KASM 1:     the stage body issues its LDS fragment reads as explicit ds_read_b128 in program order, MPG_AH MFMA
 //                   groups ahead of their use, and waits with counted `s_waitcnt lgkmcnt(n)` tied to the fragment
 //                   (the compiler otherwise sinks the reads next to their use and waits with lgkmcnt(0): one full LDS
@@ -561,8 +553,6 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 
     const int sa_hi = (127 - SA_HI) * 0x01010101;
     const int sa_lo = (127 - SA_LO) * 0x01010101;
-    const bool late = MPG_LATE_DMA && wave_u >= WAVES / 2;      // wave-uniform
-    if (MPG_PRIO && wave_u >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
 
     // The K segments are independent partial sums.  Blocks that share a CU (workgroups go round-robin over the 8
     // XCDs, then over the 32 CUs of an XCD: co-resident blocks differ in bit 8 of the id) walk them in opposite
@@ -826,7 +816,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
             // (tried: letting these image pieces stay in flight across the next barrier when their first reader is a later
             // stage, with a vmcnt chosen per stage: +2 % time -- the extra branch costs more than the wait it removes)
 #else
-            if (!late) issue_dma();
+            issue_dma();
 #endif
             MPG_STAMP(ts1);
             const char* wb = w_lds + (st % R) * WSTAGE;
@@ -966,7 +956,6 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 for (int g = 0; g < AH; ++g) read_group(g);
 #pragma unroll
                 for (int g = 0; g < 4 * NT; ++g) {
-                    if (MPG_LATE_DMA && g == 2 * NT && late) issue_dma();
                     if (g + AH < 4 * NT) read_group(g + AH);
                     // the correction operands ride behind the last fp16 groups
                     if (g >= 4 * NT - 4) read_b8(g - (4 * NT - 4));

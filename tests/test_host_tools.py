@@ -148,3 +148,39 @@ def test_tf_saver_v2_bundle_round_trip(tmp_path):
         bad = tmp_path / "bad.ckpt.index"
         bad.write_bytes(b"\\0" * 64)
         T.read_index(str(bad))
+
+
+def test_uni_streaming_codec(mpg, tmp_path):
+    """f3: chunked multi-member gzip writer / parallel reader: the decompressed stream is the reference writer's bytes
+    (fixture), any gzip reader concatenates the members, foreign single-member files still read, corruption is detected"""
+    import gzip
+    from mpgan_amd import uniio
+    dens = GOLD["uni_scalar_in"]
+    want = GOLD["uni_scalar_bytes"].tobytes()
+    n = dens.shape[0]
+    head = {"dimX": n, "dimY": n, "dimZ": n, "gridType": 1, "elementType": 1, "bytesPerElement": 4,
+            "info": b"golden".ljust(252, b"\0"), "dimT": 0, "timestamp": 1234567}
+    p = str(tmp_path / "m.uni")
+    uniio.writeUni(p, head, dens, chunk_bytes=256, threads=3)            # 4 members
+    raw = open(p, "rb").read()
+    assert len(uniio._member_sizes(raw)) == 4
+    with gzip.open(p, "rb") as f:
+        assert f.read() == want                                          # what the reference's reader sees
+    h, a = uniio.readUni(p, threads=2)
+    assert np.array_equal(a, dens) and h["timestamp"] == 1234567
+    # a foreign (single member) file
+    q = str(tmp_path / "f.uni")
+    with gzip.open(q, "wb") as f:
+        f.write(want)
+    h2, a2 = uniio.readUni(q)
+    assert np.array_equal(a2, dens) and uniio._member_sizes(open(q, "rb").read()) is None
+    # a flipped payload bit is caught by the member's crc
+    bad = bytearray(raw)
+    bad[len(bad) // 2] ^= 0x10
+    open(p, "wb").write(bytes(bad))
+    with pytest.raises((uniio.UniError, Exception)):
+        uniio.readUni(p)
+    # vec3 + larger, default settings
+    v = np.random.default_rng(3).standard_normal((20, 20, 20, 3)).astype(np.float32)
+    uniio.writeUni(p, uniio.make_header(20, 20, 20, vec3=True), v, chunk_bytes=10000)
+    assert np.array_equal(uniio.readUni(p)[1], v)
