@@ -15,8 +15,9 @@ checkpoints ``model_%04d.ckpt.npz`` and the moving-average weights ``model_ema_%
 
 ``out 1`` is the per-network output mode (see output_main).
 
-Not rebuilt: upsamplingMode 0 (the linear-interpolation variant no example run uses), adv_mode 1 / 2 (MacCormack advection), vorticity / flag / k-eps inputs, dynamic loss
-scaling (lossScaling is accepted and ignored: the arithmetic is fp32-grade), PNG test images, TensorBoard.
+Not rebuilt: upsamplingMode 0 (the linear-interpolation variant no example run uses), adv_mode 1 / 2 in the training loop (the GAN.advect kernels exist: train_ops.advect), vorticity / flag / k-eps
+inputs, PNG test images, TensorBoard.  ``lossScaling 1`` runs the dynamic loss scaling of :490-541 and every
+stage uses its own optimisers over its own variable subset (:1305-1362) -- train.StagedAdam.
 """
 import math
 import os
@@ -259,7 +260,7 @@ trainer = Trainer8x(cfg, device=device, learning_rate=learning_rate, beta1=float
                     beta2=float(P["adam_beta2"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
                     weight_dld=float(P["weight_dld"]), use_wgan_gp=int(P["use_wgan_gp"]) > 0,
                     use_LSGAN=int(P["use_LSGAN"]) > 0, seed=randSeed, use_tempo=useTempoD, lambda_t=kt,
-                    adv_flag=int(P["adv_flag"]) > 0)
+                    adv_flag=int(P["adv_flag"]) > 0, loss_scaling=int(P["lossScaling"]) > 0)
 if int(P["load_model_test"]) >= 0:
     params = checkpoint.load(checkpoint.model_path(basePath, int(P["load_model_test"]), int(P["load_model_no"])))
     with torch.no_grad():
@@ -346,19 +347,20 @@ for it in range(startingIter, trainingIterations):
     lr = poly_decay(lrgs) if decayLR else learning_rate
     for opt in [trainer.opt_d, trainer.opt_g] + ([trainer.opt_t] if useTempoD else []):
         opt.lr = lr
+    index = int(round(math.log(currentUpres, 2)) - 1)               # the growing stage's optimisers (:1978)
     for _ in range(discRuns):
         bx, by = getinput()
-        avg_d += float(trainer.disc_step(bx, by, currBlendPer)["disc_loss"].detach())
+        avg_d += float(trainer.disc_step(bx, by, currBlendPer, stage=index)["disc_loss"].detach())
     tempo = None
     if useTempoD:
         for _ in range(discRuns):
             tempo = getTempoinput()
-            trainer.tempo_disc_step(tempo[0], tempo[1], tempo[2], currBlendPer)
+            trainer.tempo_disc_step(tempo[0], tempo[1], tempo[2], currBlendPer, stage=index)
     for _ in range(genRuns):
         bx, by = getinput()
         if useTempoD:
             tempo = getTempoinput()
-        L = trainer.gen_step(bx, by, currBlendPer, tempo)
+        L = trainer.gen_step(bx, by, currBlendPer, tempo, stage=index)
         avg_g += float(L["g_loss_d"].detach())
         avg_l1 += float(L["l1_loss"].detach())
     if (it + 1) % outputInterval == 0:

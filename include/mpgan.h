@@ -276,6 +276,19 @@ int mpg_tensor_resample(mpg_stream_t stream, const float* value, const float* po
                         int clamp, float* out);
 int mpg_tensor_resample_bwd(mpg_stream_t stream, const float* dy, const float* pos, int n, int h, int w, int c,
                             int clamp, float* dvalue);
+/* One optimiser call of the 8x training loop (multipassGAN-8x.py:1305-1362 with the dynamic loss scaling of :490-541):
+ * Adam on the elements of the flat buffer whose `mask` entry is non-zero (the variables of the current growing
+ * stage; NULL = all), on the gradient times coef = exp(-ls_var ln 2) / total_grads (use_loss_scaling; the gradient
+ * buffer holds d(loss * 2^ls_var)), applied only if every such product is finite -- otherwise nothing moves and
+ * ls_var -= ls_dec; after an applied update ls_var += ls_inc and the optimiser's own step count t advances, from which
+ * lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) is formed (lr: one float in DEVICE memory).  ema_shadow (or NULL):
+ * MovingAverageOptimizer shadow of p, pulled towards the new values with (1 - ema_decay) on applied updates.
+ * state: 8 floats of device memory owned by the optimiser, [0] = ls_var, [3] = t (initialise to 64 / 0).
+ * Everything is decided on the device: a captured hipGraph of the iteration replays correctly. */
+int mpg_adam_step_staged(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, const float* mask,
+                         size_t n, float* state, const float* lr, int total_grads, int use_loss_scaling,
+                         float beta1, float beta2, float eps, float ls_inc, float ls_dec, float* ema_shadow,
+                         float ema_decay);
 /* GAN.advect (GAN.py:347-418): semi-Lagrangian / MacCormack advection of [n,h,w,c] fields (2D, h == w) for the
  * temporal-coherence branch with adv_mode 1 / 2 (multipassGAN-8x.py:1199,1225).
  *   mpg_advect_velocity: vel[n,hv,wv,cv] with channels (x, y, ..) -> out[n,h,w,2] = the (y, x) displacement the look-up

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "mpg_maccormack": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mpg_pair_reduce": (_I, [_P, _P, _P, _Z, _I, _P]),
     "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _P, _F, _F, _F]),
+    "mpg_adam_step_staged": (_I, [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _F]),
 }
 
 _lib = None

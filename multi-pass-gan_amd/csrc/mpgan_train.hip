@@ -598,6 +598,58 @@ __global__ void maccormack_kernel(const float* __restrict__ src, const float* __
     out[idx] = reject ? f : corr;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// staged Adam with dynamic loss scaling (multipassGAN-8x.py:490-541, 1305-1362), all decisions on the device so that a
+// captured hipGraph of the iteration replays them.  state (8 floats): [0] ls_var (log2 of the loss scale), [1] coef =
+// exp(-ls_var ln 2) / total_grads, [2] 1 if every scaled gradient is finite, [3] t = number of applied updates,
+// [4] lr_t of the update being attempted.
+// ---------------------------------------------------------------------------------------------
+__global__ void ls_begin_kernel(float* __restrict__ st, const float* __restrict__ lr, float inv_total, int use_ls, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    st[1] = use_ls ? inv_total * expf(-st[0] * 0.69314718f) : 1.f;      // undo_loss_scaling(1/total_grads), :528-530
+    st[2] = 1.f;
+    const float t = st[3] + 1.f;
+    st[4] = *lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+}
+
+__global__ void ls_check_kernel(const float* __restrict__ g, const float* __restrict__ mask, size_t n, float* __restrict__ st) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    if (mask != nullptr && mask[idx] == 0.f) return;
+    if (!isfinite(g[idx] * st[1])) st[2] = 0.f;                          // tf.reduce_all(tf.is_finite(g)), :533-534
+}
+
+// masked Adam on the scaled gradient; skipped as a whole when the finite check failed (tf.cond, :537-539)
+__global__ void adam_staged_kernel(float* __restrict__ p, const float* __restrict__ gr, float* __restrict__ m,
+                                   float* __restrict__ v, const float* __restrict__ mask, size_t n,
+                                   const float* __restrict__ st, float b1, float b2, float eps, float* __restrict__ shadow,
+                                   float ema_decay) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    if (st[2] == 0.f) return;
+    if (mask != nullptr && mask[idx] == 0.f) return;
+    const float g = gr[idx] * st[1];
+    const float mm = m[idx] + (g - m[idx]) * (1.f - b1);
+    const float vv = v[idx] + (g * g - v[idx]) * (1.f - b2);
+    m[idx] = mm;
+    v[idx] = vv;
+    const float pn = p[idx] - st[4] * mm / (sqrtf(vv) + eps);
+    p[idx] = pn;
+    // tf.contrib.opt.MovingAverageOptimizer: shadow -= (1 - decay) (shadow - var) after the update (:1356)
+    if (shadow != nullptr) shadow[idx] -= (1.f - ema_decay) * (shadow[idx] - pn);
+}
+
+__global__ void ls_end_kernel(float* __restrict__ st, int use_ls, float inc, float dec) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st[2] != 0.f) {
+        st[3] += 1.f;
+        if (use_ls) st[0] += inc;                                        // tf.assign_add(ls_var, loss_scaling_inc)
+    } else if (use_ls) {
+        st[0] -= dec;                                                    // tf.assign_sub(ls_var, loss_scaling_dec)
+    }
+}
+
 }  // namespace
 
 #define MPG_GEOM_CHECK(NAME)                                                                                  \
@@ -794,6 +846,22 @@ extern "C" int mpg_adam_step(mpg_stream_t stream, float* p, const float* grad, f
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, p, grad, m, v, n, lr_t,
                        beta1, beta2, eps);
     MPG_LAUNCH_CHECK("adam_kernel");
+}
+
+extern "C" int mpg_adam_step_staged(mpg_stream_t stream, float* p, const float* grad, float* m, float* v, const float* mask,
+                                    size_t n, float* state, const float* lr, int total_grads, int use_loss_scaling,
+                                    float beta1, float beta2, float eps, float ls_inc, float ls_dec, float* ema_shadow,
+                                    float ema_decay) {
+    MPG_REQUIRE(p && grad && m && v && state && lr, "mpg_adam_step_staged: null pointer");
+    MPG_REQUIRE(total_grads >= 1, "mpg_adam_step_staged: total_grads %d", total_grads);
+    if (n == 0) return MPG_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ls_begin_kernel, dim3(1), dim3(64), 0, s, state, lr, 1.f / (float)total_grads, use_loss_scaling, beta1, beta2);
+    if (use_loss_scaling) hipLaunchKernelGGL(ls_check_kernel, dim3(grid_for(n)), dim3(BLK), 0, s, grad, mask, n, state);
+    hipLaunchKernelGGL(adam_staged_kernel, dim3(grid_for(n)), dim3(BLK), 0, s, p, grad, m, v, mask, n, state, beta1, beta2, eps,
+                       ema_shadow, ema_decay);
+    hipLaunchKernelGGL(ls_end_kernel, dim3(1), dim3(64), 0, s, state, use_loss_scaling, ls_inc, ls_dec);
+    MPG_LAUNCH_CHECK("adam_staged_kernel");
 }
 
 extern "C" int mpg_advect_velocity(mpg_stream_t stream, const float* vel, int n, int hv, int wv, int cv, int h, int w, float dt,

@@ -646,6 +646,90 @@ class AdamTF(object):
         train_ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr_t, self.b1, self.b2, self.eps)
 
 
+def stage_variable_names(names, stage, levels):
+    """the variables stage z of the growing schedule optimises (multipassGAN-8x.py:1316-1321,1331-1336,1347-1352): all of
+    them at the last stage, otherwise those whose TF name contains one of "1", "2", .., "2^(z+1)" as a substring"""
+    if stage >= levels - 1:
+        return list(names)
+    keys = ["%i" % (2 ** i) for i in range(stage + 2)]
+    return [n for n in names if any(k in n for k in keys)]
+
+
+class StagedAdam(AdamTF):
+    """The optimisers of one network of the 8x training graph (multipassGAN-8x.py:1305-1362): per growing stage an Adam
+    with its OWN moments and step count over that stage's variable subset (a fresh one takes over at every stage change;
+    `copyAdamVariables` (:1783-1802) builds assign ops it never runs and then re-initialises the new stage's slots, i.e.
+    changes nothing), optional dynamic loss scaling (:490-541: the loss is multiplied by 2^ls_var, gradients by
+    2^-ls_var / len(grads); a non-finite gradient skips the update and lowers ls_var by 1, an applied one raises it by
+    0.0005), and for the generator the MovingAverageOptimizer shadows of each stage (:1356).
+    One flat parameter buffer; the stage's subset is a 0/1 mask over it; every decision is taken on the device."""
+
+    LS_INIT, LS_INC, LS_DEC = 64.0, 0.0005, 1.0
+
+    def __init__(self, params, levels, lr=1e-4, beta1=0.0, beta2=0.99, eps=1e-8, comm=None, loss_scaling=False,
+                 ema_decay=None):
+        super().__init__(params, lr, beta1, beta2, eps, comm)
+        dev = self.flat.device
+        self.levels, self.loss_scaling, self.ema_decay = levels, bool(loss_scaling), ema_decay
+        n = self.flat.numel()
+        self.masks, self.counts = [], []
+        for z in range(levels):
+            chosen = set(stage_variable_names(self.names, z, levels))
+            mask = torch.zeros(n, dtype=torch.float32, device=dev)
+            off = 0
+            for name, p in zip(self.names, self.params):
+                if name in chosen:
+                    mask[off:off + p.numel()] = 1.0
+                off += p.numel()
+            self.masks.append(None if len(chosen) == len(self.names) else mask)
+            self.counts.append(len(chosen))
+        self.ms = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(levels)]
+        self.vs = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in range(levels)]
+        # per stage: [ls_var, coef, ok, t, lr_t, -, -, -]; ls_var is ONE variable per network in the reference (:501-503)
+        self.state = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in range(levels)]
+        for st in self.state:
+            st[0] = self.LS_INIT
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.shadows = None
+        if ema_decay is not None:       # shadows start from the variables' initial values
+            self.shadows = [self.flat.detach().clone() for _ in range(levels)]
+        self._last_stage = None
+
+    def loss_scale(self, stage):
+        """2^ls_var as a device scalar (apply_loss_scaling, :506-507); 1 when loss scaling is off"""
+        if not self.loss_scaling:
+            return None
+        return torch.exp(self.state[stage][0] * math.log(2.0))
+
+    def step(self, grads, lr=None, stage=None):
+        stage = self.levels - 1 if stage is None else int(stage)
+        if self.loss_scaling and self._last_stage is not None and stage != self._last_stage:
+            self.state[stage][0] = self.state[self._last_stage][0]       # the network's single ls_var moves on with it
+        self._last_stage = stage
+        if lr is not None:
+            self.lr = lr
+        self.lr_dev.fill_(float(self.lr))
+        if any(g is None for g in grads):
+            self.grad.zero_()
+        dst = [v for v, g in zip(self._grad_views, grads) if g is not None]
+        torch._foreach_copy_(dst, [g.contiguous() for g in grads if g is not None])
+        if self.comm is not None:
+            self.comm.all_reduce_mean(self.grad)
+        train_ops.adam_step_staged(self.flat, self.grad, self.ms[stage], self.vs[stage], self.masks[stage], self.state[stage],
+                                   self.lr_dev, self.counts[stage], self.loss_scaling, self.b1, self.b2, self.eps,
+                                   self.LS_INC, self.LS_DEC, None if self.shadows is None else self.shadows[stage],
+                                   self.ema_decay if self.ema_decay is not None else 0.0)
+
+    def ema_params(self, stage=None):
+        """name -> moving-average tensor of the stage's shadows (swapping_saver of the last stage's optimiser, :1369)"""
+        stage = self.levels - 1 if stage is None else stage
+        out, off = {}, 0
+        for name, p in zip(self.names, self.params):
+            out[name] = self.shadows[stage][off:off + p.numel()].view(p.shape)
+            off += p.numel()
+        return out
+
+
 def sigmoid_ce(logits, label):
     """tf.nn.sigmoid_cross_entropy_with_logits, mean over the batch: max(x,0) - x*z + log(1+exp(-|x|))"""
     return (torch.clamp(logits, min=0) - logits * label + torch.log1p(torch.exp(-logits.abs()))).mean()
@@ -839,7 +923,7 @@ class Trainer8x(object):
     def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
                  prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999, use_tempo=False, lambda_t=1.0,
-                 adv_flag=True, clamping=True):
+                 adv_flag=True, clamping=True, loss_scaling=False):
         from . import arch
         from .session import VariableStore
         self.cfg = cfg
@@ -890,13 +974,15 @@ class Trainer8x(object):
             self.sess.higher_order_scopes = ("spatial-disc", "tempo-disc")
         self.g_var = self.sess.trainable("g_")
         self.d_var = self.sess.trainable("d_")
-        self.opt_d = AdamTF(self.d_var, learning_rate, beta1, beta2, comm=comm)
-        self.opt_g = AdamTF(self.g_var, learning_rate, beta1, beta2, comm=comm)
+        lv = self.currentUpres
+        self.loss_scaling = bool(loss_scaling)
+        self.opt_d = StagedAdam(self.d_var, lv, learning_rate, beta1, beta2, comm=comm, loss_scaling=loss_scaling)
+        self.opt_g = StagedAdam(self.g_var, lv, learning_rate, beta1, beta2, comm=comm, loss_scaling=loss_scaling,
+                                ema_decay=ema_decay)
         if use_tempo:
             self.t_var = {n: p for n, p in self.sess.trainable("t_").items() if n.startswith("tempo-disc")}
-            self.opt_t = AdamTF(self.t_var, learning_rate, beta1, beta2, comm=comm)
+            self.opt_t = StagedAdam(self.t_var, lv, learning_rate, beta1, beta2, comm=comm, loss_scaling=loss_scaling)
         self.ema_decay = ema_decay
-        self.ema = [p.detach().clone() for p in self.opt_g.params]
         self.rng = torch.Generator(device="cpu").manual_seed(seed)
 
     # ------------------------------------------------------------------ losses
@@ -1015,36 +1101,44 @@ class Trainer8x(object):
         L["g_loss_t"] = self._adv(gen_s, True)
         return L
 
-    def tempo_disc_step(self, batch_xts, batch_yts, batch_y_pos=None, percentage=3.0, lerp_factor=None):
+    @property
+    def ema(self):
+        """moving averages of the generator variables as the last stage's optimiser keeps them (the model_ema checkpoint)"""
+        return list(self.opt_g.ema_params().values())
+
+    def _update(self, opt, loss, stage):
+        """calc_gradients + apply_updates (:510-541): d(loss * 2^ls_var) for ALL of the network's variables; the stage's
+        mask selects the ones its optimiser owns (unconnected ones count as zeros, :516)"""
+        scale = opt.loss_scale(opt.levels - 1 if stage is None else stage)
+        grads = torch.autograd.grad(loss if scale is None else loss * scale, opt.params, allow_unused=True)
+        opt.step(grads, stage=stage)
+
+    def tempo_disc_step(self, batch_xts, batch_yts, batch_y_pos=None, percentage=3.0, lerp_factor=None, stage=None):
         L = self.tempo_losses(batch_xts, batch_yts, batch_y_pos, percentage, lerp_factor)
-        grads = torch.autograd.grad(L["t_disc_loss"], self.opt_t.params, allow_unused=True)
-        self.opt_t.step(grads)
+        self._update(self.opt_t, L["t_disc_loss"], stage)
         return L
 
-    def disc_step(self, batch_xs, batch_ys, percentage=3.0, lerp_factor=None):
+    def disc_step(self, batch_xs, batch_ys, percentage=3.0, lerp_factor=None, stage=None):
         L = self.losses(batch_xs, batch_ys, percentage, lerp_factor)
-        grads = torch.autograd.grad(L["disc_loss"], self.opt_d.params, allow_unused=True)
-        self.opt_d.step(grads)
+        self._update(self.opt_d, L["disc_loss"], stage)
         return L
 
-    def gen_step(self, batch_xs, batch_ys, percentage=3.0, tempo=None):
+    def gen_step(self, batch_xs, batch_ys, percentage=3.0, tempo=None, stage=None):
         L = self.losses(batch_xs, batch_ys, percentage, need_gp=False)
         if tempo is not None:
             Lt = self.tempo_losses(tempo[0], tempo[1], tempo[2], percentage, need_gp=False)
             L.update(Lt)
             L["gen_loss_complete"] = L["gen_loss_complete"] + self.kt * Lt["g_loss_t"]        # :1302
-        grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
-        self.opt_g.step(grads)
-        with torch.no_grad():       # MovingAverageOptimizer(…, 0.999): shadow += (1 - decay) * (var - shadow)
-            torch._foreach_lerp_(self.ema, [p.detach() for p in self.opt_g.params], 1.0 - self.ema_decay)
+        self._update(self.opt_g, L["gen_loss_complete"], stage)     # the moving averages move inside the optimiser call
         return L
 
-    def train_step(self, batch_xs, batch_ys, percentage=3.0, discRuns=1, genRuns=1, tempo=None):
+    def train_step(self, batch_xs, batch_ys, percentage=3.0, discRuns=1, genRuns=1, tempo=None, stage=None):
+        """stage: index of the growing stage's optimisers, log2(currentUpres) - 1 (:1978); None = the last one"""
         for _ in range(discRuns):
-            Ld = self.disc_step(batch_xs, batch_ys, percentage)
+            Ld = self.disc_step(batch_xs, batch_ys, percentage, stage=stage)
         if tempo is not None:
             for _ in range(discRuns):
-                self.tempo_disc_step(tempo[0], tempo[1], tempo[2], percentage)
+                self.tempo_disc_step(tempo[0], tempo[1], tempo[2], percentage, stage=stage)
         for _ in range(genRuns):
-            Lg = self.gen_step(batch_xs, batch_ys, percentage, tempo)
+            Lg = self.gen_step(batch_xs, batch_ys, percentage, tempo, stage=stage)
         return Ld["disc_loss"].detach(), Lg["gen_loss_complete"].detach()

@@ -185,6 +185,16 @@ def tensor_resample_bwd(dy, pos, clamp=True):
     return dv
 
 
+def adam_step_staged(p, grad, m, v, mask, state, lr, total_grads, use_loss_scaling, beta1, beta2, eps=1e-8, ls_inc=0.0005,
+                     ls_dec=1.0, ema_shadow=None, ema_decay=0.999):
+    """one optimiser call of multipassGAN-8x.py:1305-1362 / 490-541 on flat fp32 buffers (mpg_adam_step_staged)"""
+    lib = _lib.load()
+    rc = lib.mpg_adam_step_staged(_stream(), _ptr(p), _ptr(grad), _ptr(m), _ptr(v), _ptr(mask), p.numel(), _ptr(state), _ptr(lr),
+                                  int(total_grads), int(bool(use_loss_scaling)), float(beta1), float(beta2), float(eps),
+                                  float(ls_inc), float(ls_dec), _ptr(ema_shadow), float(ema_decay))
+    _lib.check(rc, "mpg_adam_step_staged")
+
+
 def advect_velocity(vel, h, w, dt):
     """the (y, x) displacement field GAN.advect looks up with (GAN.py:376-396): vel [n,hv,wv,>=2] (x,y,..) -> [n,h,w,2]"""
     lib = _lib.load()

@@ -292,3 +292,69 @@ def losses_8x(p, batch_xs, batch_ys, tile_low, channels, percentage=3.0, lerp_fa
     L["disc_loss"] = disc_loss
     L["gen_loss_complete"] = L["g_loss_d"] + L["l1_loss"] * lambda_l1 + L["disc_loss_layer"] * lambda2
     return L
+
+
+# ----------------------------------------------------------------------------------------------
+# the optimiser call (multipassGAN-8x.py:490-541, 1305-1362), float64 numpy
+# ----------------------------------------------------------------------------------------------
+def stage_variables(names, stage, levels):
+    """:1316-1321: every variable at the last stage; before that, names containing "1", "2", .., "2^(stage+1)" """
+    if stage >= levels - 1:
+        return list(names)
+    keys = ["%i" % (2 ** i) for i in range(stage + 2)]
+    return [n for n in names if any(k in n for k in keys)]
+
+
+class StagedAdamRef(object):
+    """per stage an Adam (own m, v, t) over its variable subset; optional dynamic loss scaling with ONE ls_var;
+    optional MovingAverageOptimizer shadows per stage.  grads passed to step() are d(loss * 2^ls_var)."""
+
+    def __init__(self, params, levels, lr=1e-4, beta1=0.0, beta2=0.99, eps=1e-8, loss_scaling=False, ema_decay=None):
+        import numpy as np
+        self.np = np
+        self.p = {k: np.array(v, dtype=np.float64) for k, v in params.items()}
+        self.names = sorted(self.p)
+        self.levels, self.lr, self.b1, self.b2, self.eps = levels, lr, beta1, beta2, eps
+        self.loss_scaling, self.ema_decay = loss_scaling, ema_decay
+        self.m = [{k: np.zeros_like(v) for k, v in self.p.items()} for _ in range(levels)]
+        self.v = [{k: np.zeros_like(v) for k, v in self.p.items()} for _ in range(levels)]
+        self.t = [0] * levels
+        self.ls_var = np.float32(64.0)
+        self.shadow = None if ema_decay is None else [{k: v.copy() for k, v in self.p.items()} for _ in range(levels)]
+
+    def loss_scale(self):
+        np = self.np
+        return float(np.exp(np.float32(self.ls_var) * np.float32(np.log(2.0)))) if self.loss_scaling else 1.0
+
+    def step(self, grads, stage):
+        """grads: name -> array (missing = zero).  Returns True if the update was applied."""
+        np = self.np
+        sel = stage_variables(self.names, stage, self.levels)
+        coef = 1.0
+        if self.loss_scaling:
+            with np.errstate(all="ignore"):
+                coef = np.float32(1.0 / len(sel)) * np.exp(-np.float32(self.ls_var) * np.float32(np.log(2.0)))
+        scaled = {}
+        ok = True
+        with np.errstate(all="ignore"):
+            for k in sel:
+                g = np.asarray(grads.get(k, np.zeros_like(self.p[k])), dtype=np.float32) * np.float32(coef)
+                ok = ok and bool(np.isfinite(g).all())
+                scaled[k] = g.astype(np.float64)
+        if self.loss_scaling and not ok:
+            self.ls_var = np.float32(self.ls_var - 1.0)
+            return False
+        self.t[stage] += 1
+        t = self.t[stage]
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        for k in sel:
+            g = scaled[k]
+            m, v = self.m[stage][k], self.v[stage][k]
+            m += (g - m) * (1.0 - self.b1)
+            v += (g * g - v) * (1.0 - self.b2)
+            self.p[k] -= lr_t * m / (np.sqrt(v) + self.eps)
+            if self.shadow is not None:
+                self.shadow[stage][k] -= (1.0 - self.ema_decay) * (self.shadow[stage][k] - self.p[k])
+        if self.loss_scaling:
+            self.ls_var = np.float32(self.ls_var + np.float32(0.0005))
+        return True

@@ -246,3 +246,88 @@ def test_second_network_temporal_branch():
     ys2 = rng.random((2, 32 * 32 * 2)).astype(np.float32)
     d, g = tr.train_step(xs, ys2, 3.0, tempo=(xts, yts, ypos))
     assert np.isfinite(float(d)) and np.isfinite(float(g))
+
+
+# ---------------------------------------------------------------------------------------------
+# a10: per-stage optimisers, dynamic loss scaling with the skip-on-overflow update, moving averages
+# ---------------------------------------------------------------------------------------------
+def test_stage_variable_subsets_match_the_reference_rule():
+    """multipassGAN-8x.py:1316-1321: substring rule on the TF variable names"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd.train import stage_variable_names
+    from oracle import train_ref8x as TR8
+    names = ["generator/genBlock2/g_cA_first/weight", "generator/genBlock4/g_cB_third/bias", "generator/genBlock8/g_cdensOut8/weight",
+             "generator/g_cdensOut1/weight", "generator/genBlock2/g_cdensOut2/bias", "spatial-disc/d_cfromDensity8/weight",
+             "spatial-disc/dBlock2/d_cA2/weight", "spatial-disc/d_l61/bias", "spatial-disc/d_cfromDensity4/weight",
+             "generator/g_cA_1/weight", "tempo-disc/tBlock8/t_cB8/weight"]
+    for z in range(3):
+        assert stage_variable_names(names, z, 3) == TR8.stage_variables(names, z, 3)
+    s0 = stage_variable_names(names, 0, 3)
+    assert "generator/genBlock4/g_cB_third/bias" not in s0 and "generator/genBlock2/g_cA_first/weight" in s0
+    assert "spatial-disc/d_l61/bias" in s0 and "spatial-disc/d_cfromDensity8/weight" not in s0
+    assert "spatial-disc/d_cfromDensity4/weight" in stage_variable_names(names, 1, 3)
+    assert stage_variable_names(names, 2, 3) == names
+
+
+@pytest.mark.parametrize("loss_scaling", [False, True])
+def test_staged_adam_against_float64_reference(loss_scaling):
+    """train.StagedAdam / mpg_adam_step_staged against oracle.train_ref8x.StagedAdamRef: stage subsets with their own
+    moments, fresh optimiser at a stage change, loss-scale bookkeeping incl. one forced overflow (update skipped,
+    ls_var lowered), moving-average shadows -- with the same synthetic gradients fed to both"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd.train import StagedAdam
+    from oracle import train_ref8x as TR8
+    rng = np.random.default_rng(5)
+    shapes = {"generator/genBlock2/g_cA_first/weight": (3, 3, 6, 8), "generator/genBlock2/g_cA_first/bias": (8,),
+              "generator/genBlock4/g_cB_third/weight": (3, 3, 8, 4), "generator/genBlock8/g_cdensOut8/weight": (1, 1, 4, 1),
+              "generator/g_cdensOut1/bias": (1,)}
+    init = {k: rng.standard_normal(s).astype(np.float32) for k, s in shapes.items()}
+    params = {k: torch.tensor(v, device="cuda:0", requires_grad=True) for k, v in init.items()}
+    opt = StagedAdam(params, 3, lr=1e-3, beta1=0.0, beta2=0.99, loss_scaling=loss_scaling, ema_decay=0.999)
+    ref = TR8.StagedAdamRef(init, 3, lr=1e-3, beta1=0.0, beta2=0.99, loss_scaling=loss_scaling, ema_decay=0.999)
+    assert opt.counts == [len(TR8.stage_variables(sorted(init), z, 3)) for z in range(3)]
+    plan = [(0, False), (0, False), (0, True), (0, False), (1, False), (1, False), (2, True), (2, False), (2, False)]
+    for step, (stage, overflow) in enumerate(plan):
+        scale = ref.loss_scale()
+        if loss_scaling:
+            assert abs(float(opt.loss_scale(stage)) / scale - 1.0) < 1e-5
+        grads = {k: (rng.standard_normal(s) * 1e-2).astype(np.float32) * np.float32(scale) for k, s in shapes.items()}
+        if overflow:
+            grads["generator/genBlock2/g_cA_first/weight"][0, 0, 0, 0] = np.inf
+        applied = ref.step(grads, stage)
+        opt.step([torch.tensor(grads[k], device="cuda:0") for k in opt.names], stage=stage)
+        if overflow and loss_scaling:
+            assert not applied
+        if overflow and not loss_scaling:
+            break            # without loss scaling TensorFlow applies the infinite gradient: not a case worth pinning
+        for k in opt.names:
+            got = params[k].detach().cpu().numpy()
+            assert np.allclose(got, ref.p[k], rtol=2e-5, atol=2e-6), (step, k)
+            ema = opt.ema_params(stage)[k].cpu().numpy()
+            assert np.allclose(ema, ref.shadow[stage][k], rtol=2e-5, atol=2e-6), (step, k)
+        if loss_scaling:
+            assert abs(float(opt.state[stage][0]) - float(ref.ls_var)) < 1e-4
+            assert int(opt.state[stage][3]) == ref.t[stage]
+
+
+def test_trainer8x_loss_scaling_step_matches_unscaled_direction():
+    """Trainer8x with lossScaling 1 at stage 0: the loss is scaled by 2^64, gradients come back through the fp16-split
+    kernels, are unscaled by 2^-64 / len(vars) on the device and applied; nothing overflows, ls_var rises by 0.0005 per
+    optimiser call, only stage-0 variables move"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd.arch import Cfg8x
+    from mpgan_amd.train import Trainer8x, stage_variable_names
+    cfg = Cfg8x(tileSizeLow=4, upRes=8, n_inputChannels=6, start_fms=32, max_fms=32)
+    tr = Trainer8x(cfg, seed=3, loss_scaling=True)
+    rng = np.random.default_rng(2)
+    xs = rng.random((3, cfg.n_input)).astype(np.float32)
+    ys = rng.random((3, (4 * 2) ** 2)).astype(np.float32)       # stage-0 targets at 2x
+    before = {n: p.detach().clone() for n, p in zip(tr.opt_g.names, tr.opt_g.params)}
+    tr.disc_step(xs, ys, 1.0, stage=0)
+    tr.gen_step(xs, ys, 1.0, stage=0)
+    moving = set(stage_variable_names(tr.opt_g.names, 0, 3))
+    moved = {n for n, p in zip(tr.opt_g.names, tr.opt_g.params) if not torch.equal(p.detach(), before[n])}
+    assert moved and moved <= moving
+    assert abs(float(tr.opt_g.state[0][0]) - 64.0005) < 1e-4 and float(tr.opt_g.state[0][2]) == 1.0
+    assert abs(float(tr.opt_d.state[0][0]) - 64.0005) < 1e-4
+    assert all(torch.isfinite(p).all() for p in tr.opt_g.params)
