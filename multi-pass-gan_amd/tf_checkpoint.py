@@ -14,9 +14,11 @@ here):
   BundleEntryProto value: dtype (1), shape (2), shard_id (3), offset (4), size (5), crc32c (6).
 * ``.data-*`` is the concatenation of the raw little-endian tensor bytes.
 
-STATUS: no TensorFlow-written file exists in this container to test against; the reader is pinned only by
-round trips through the writer below (same restated format).  float32 / float64 / int32 / int64 tensors,
-single shard, no slices.
+STATUS: no TensorFlow-written file exists in this container to test against.  The reader is pinned by (a) the
+published crc32c check values (RFC 3720 B.4) and LevelDB's mask, (b) index files assembled by a second, independent
+builder in tests/test_host_tools.py (several data blocks, restart intervals 1 / 3 / 16 with and without prefix
+sharing, corrupted block and tensor checksums, out-of-order keys, a snappy-tagged block), and (c) round trips through
+the writer below.  float32 / float64 / int32 / int64 tensors, single shard, no slices.
 """
 import os
 import struct
@@ -129,10 +131,17 @@ def _mask(crc):
 
 
 # ---------------------------------------------------------------- sorted string table
-def _read_block(data, offset, size):
+def _read_block(data, offset, size, verify=True):
+    """block contents at `offset`; the 5-byte trailer (compression tag, masked crc32c of contents + tag) is checked"""
+    if offset + size + 5 > len(data):
+        raise CheckpointFormatError("block handle (%d, %d) points past the end of the file" % (offset, size))
     tag = data[offset + size]
     if tag != 0:
         raise CheckpointFormatError("compressed index block (type %d): only uncompressed bundles are supported" % tag)
+    if verify:
+        stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+        if stored != _mask(_crc32c(data[offset:offset + size + 1])):
+            raise CheckpointFormatError("block at offset %d fails its crc32c" % offset)
     return data[offset:offset + size]
 
 
@@ -142,10 +151,14 @@ def _block_entries(block):
     n_restarts = struct.unpack_from("<I", block, len(block) - 4)[0]
     end = len(block) - 4 - 4 * n_restarts
     pos, key, out = 0, b"", []
+    if end < 0:
+        raise CheckpointFormatError("restart array larger than its block")
     while pos < end:
         shared, pos = _get_varint(block, pos)
         non_shared, pos = _get_varint(block, pos)
         vlen, pos = _get_varint(block, pos)
+        if shared > len(key) or pos + non_shared + vlen > end:
+            raise CheckpointFormatError("corrupt block entry")
         key = key[:shared] + bytes(block[pos:pos + non_shared])
         pos += non_shared
         out.append((key, bytes(block[pos:pos + vlen])))
@@ -153,8 +166,8 @@ def _block_entries(block):
     return out
 
 
-def read_index(path):
-    """-> {key bytes: value bytes} of a sorted string table file"""
+def read_index(path, verify=True):
+    """-> {key bytes: value bytes} of a sorted string table file (block checksums verified unless verify=False)"""
     with open(path, "rb") as f:
         data = f.read()
     if len(data) < 48 or struct.unpack_from("<Q", data, len(data) - 8)[0] != MAGIC:
@@ -165,17 +178,22 @@ def read_index(path):
     ioff, p = _get_varint(foot, p)
     isize, p = _get_varint(foot, p)
     table = {}
-    for _, handle in _block_entries(_read_block(data, ioff, isize)):
+    last = None
+    for _, handle in _block_entries(_read_block(data, ioff, isize, verify)):
         boff, q = _get_varint(handle, 0)
         bsize, q = _get_varint(handle, q)
-        for k, v in _block_entries(_read_block(data, boff, bsize)):
+        for k, v in _block_entries(_read_block(data, boff, bsize, verify)):
+            if last is not None and k <= last:
+                raise CheckpointFormatError("keys out of order in the index (%r after %r)" % (k, last))
             table[k] = v
+            last = k
     return table
 
 
-def read_checkpoint(prefix):
-    """{variable name: numpy array} of the Saver-V2 checkpoint ``prefix`` (.index + .data-00000-of-00001)"""
-    table = read_index(prefix + ".index")
+def read_checkpoint(prefix, verify=True):
+    """{variable name: numpy array} of the Saver-V2 checkpoint ``prefix`` (.index + .data-00000-of-00001); block and
+    tensor crc32c values are verified unless verify=False"""
+    table = read_index(prefix + ".index", verify)
     header = dict((n, v) for n, _, v in _parse_message(table.get(b"", b"")))
     if header.get(1, 1) != 1:
         raise CheckpointFormatError("%d shards: only single-shard checkpoints are supported" % header.get(1))
@@ -187,7 +205,7 @@ def read_checkpoint(prefix):
     for key, val in table.items():
         if key == b"":
             continue
-        e = {"dtype": 0, "shape": (), "offset": 0, "size": 0, "slices": False}
+        e = {"dtype": 0, "shape": (), "offset": 0, "size": 0, "slices": False, "crc": None}
         for num, _, v in _parse_message(val):
             if num == 1:
                 e["dtype"] = v
@@ -197,6 +215,8 @@ def read_checkpoint(prefix):
                 e["offset"] = v
             elif num == 5:
                 e["size"] = v
+            elif num == 6:
+                e["crc"] = v
             elif num == 7:
                 e["slices"] = True
         name = key.decode("utf-8")
@@ -206,6 +226,8 @@ def read_checkpoint(prefix):
         n = int(np.prod(e["shape"], dtype=np.int64)) if e["shape"] else 1
         if n * dt.itemsize != e["size"] or e["offset"] + e["size"] > len(blob):
             raise CheckpointFormatError("entry %s: %d bytes for shape %s" % (name, e["size"], e["shape"]))
+        if verify and e["crc"] is not None and e["crc"] != _mask(_crc32c(blob[e["offset"]:e["offset"] + e["size"]])):
+            raise CheckpointFormatError("tensor %s fails its crc32c" % name)
         out[name] = np.frombuffer(blob, dtype=dt.newbyteorder("<"), count=n, offset=e["offset"]).reshape(e["shape"]).astype(dt)
     return out
 

@@ -184,3 +184,115 @@ def test_uni_streaming_codec(mpg, tmp_path):
     v = np.random.default_rng(3).standard_normal((20, 20, 20, 3)).astype(np.float32)
     uniio.writeUni(p, uniio.make_header(20, 20, 20, vec3=True), v, chunk_bytes=10000)
     assert np.array_equal(uniio.readUni(p)[1], v)
+
+
+# ---------------------------------------------------------------------------------------------
+# f1: TF Saver-V2 reader against hand-assembled tables (second, independent builder) and known check values
+# ---------------------------------------------------------------------------------------------
+def _vi(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7f) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _table(blocks, restart_interval, share_prefixes, tf_ck, corrupt_block=None, tag=0):
+    """LevelDB table: `blocks` = list of lists of (key, value); returns file bytes.  Written independently of
+    tf_checkpoint.write_checkpoint: other restart intervals, optional absence of prefix sharing."""
+    import struct
+    out = bytearray()
+
+    def block(kvs, interval, share):
+        b, restarts, last = bytearray(), [], b""
+        for i, (k, v) in enumerate(kvs):
+            sh = 0
+            if i % interval == 0:
+                restarts.append(len(b))
+            elif share:
+                while sh < min(len(k), len(last)) and k[sh] == last[sh]:
+                    sh += 1
+            b += _vi(sh) + _vi(len(k) - sh) + _vi(len(v)) + k[sh:] + v
+            last = k
+        if not restarts:
+            restarts = [0]
+        for r in restarts:
+            b += struct.pack("<I", r)
+        return bytes(b + struct.pack("<I", len(restarts)))
+
+    def emit(blk, t=0, bad=False):
+        off = len(out)
+        crc = tf_ck._mask(tf_ck._crc32c(blk + bytes([t])))
+        out.extend(blk + bytes([t]) + struct.pack("<I", crc ^ (1 if bad else 0)))
+        return _vi(off) + _vi(len(blk))
+
+    handles = []
+    for i, kvs in enumerate(blocks):
+        handles.append((kvs[-1][0], emit(block(kvs, restart_interval, share_prefixes), tag if i == 0 else 0, corrupt_block == i)))
+    meta = emit(block([], 1, False))
+    idx = emit(block(handles, 1, False))
+    foot = meta + idx
+    out.extend(foot + b"\0" * (40 - len(foot)) + struct.pack("<Q", tf_ck.MAGIC))
+    return bytes(out)
+
+
+def test_tf_checkpoint_reader_on_hand_built_tables(mpg, tmp_path):
+    import struct
+    from mpgan_amd import tf_checkpoint as ck
+    # crc32c check values of RFC 3720 B.4 and the LevelDB mask (Mask(crc32c("foo")) is not crc32c("foo"), and unmasking restores it)
+    assert ck._crc32c(b"123456789") == 0xe3069283
+    assert ck._crc32c(bytes(32)) == 0x8a9136aa and ck._crc32c(b"\xff" * 32) == 0x62a8ab43
+    assert ck._crc32c(bytes(range(32))) == 0x46dd794e
+    m = ck._mask(ck._crc32c(b"foo"))
+    assert m != ck._crc32c(b"foo") and ((((m - 0xa282ead8) & 0xffffffff) >> 17) | (((m - 0xa282ead8) & 0xffffffff) << 15)) & 0xffffffff == ck._crc32c(b"foo")
+    rng = np.random.default_rng(1)
+    tensors = {"generator/genBlock%d/g_c%s_%s/%s" % (b, ab, nm, wb): rng.standard_normal(shp).astype(np.float32)
+               for b in (2, 4, 8) for ab in "AB" for nm in ("first", "second") for wb, shp in (("weight", (3, 3, 2, 4)), ("bias", (4,)))}
+    tensors["global_step"] = np.array(7, dtype=np.int64)
+    names = sorted(tensors, key=lambda s: s.encode())
+    blob, entries = bytearray(), []
+    for nme in names:
+        raw = tensors[nme].tobytes()
+        entries.append((nme.encode(), ck._entry_proto(ck.DTYPE_IDS[tensors[nme].dtype], tensors[nme].shape, len(blob), len(raw),
+                                                      ck._mask(ck._crc32c(raw)))))
+        blob += raw
+    header = b"\x08\x01"                                  # BundleHeaderProto { num_shards: 1 }
+    items = [(b"", header)] + entries
+    prefix = str(tmp_path / "model_0001.ckpt")
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(blob))
+    for interval, share, nblocks in ((1, False, 1), (3, True, 4), (16, True, 2), (5, True, len(items))):
+        per = -(-len(items) // nblocks)
+        blocks = [items[i:i + per] for i in range(0, len(items), per)]
+        open(prefix + ".index", "wb").write(_table(blocks, interval, share, ck))
+        got = ck.read_checkpoint(prefix)
+        assert sorted(got) == sorted(tensors)
+        for k in tensors:
+            assert got[k].dtype == tensors[k].dtype and np.array_equal(got[k], tensors[k]), (interval, k)
+    blocks = [items[:9], items[9:]]
+    # a data block whose checksum is wrong
+    open(prefix + ".index", "wb").write(_table(blocks, 4, True, ck, corrupt_block=1))
+    with pytest.raises(ck.CheckpointFormatError, match="crc32c"):
+        ck.read_checkpoint(prefix)
+    assert sorted(ck.read_checkpoint(prefix, verify=False)) == sorted(tensors)
+    # a snappy-compressed block is refused, not mis-read
+    open(prefix + ".index", "wb").write(_table(blocks, 4, True, ck, tag=1))
+    with pytest.raises(ck.CheckpointFormatError, match="compressed"):
+        ck.read_checkpoint(prefix)
+    # keys out of order
+    open(prefix + ".index", "wb").write(_table([items[9:], items[:9]], 4, True, ck))
+    with pytest.raises(ck.CheckpointFormatError, match="order"):
+        ck.read_checkpoint(prefix)
+    # a flipped bit in a tensor
+    open(prefix + ".index", "wb").write(_table(blocks, 4, True, ck))
+    bad = bytearray(blob)
+    bad[100] ^= 0x40
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(bad))
+    with pytest.raises(ck.CheckpointFormatError, match="tensor"):
+        ck.read_checkpoint(prefix)
+    # wrong magic
+    raw = bytearray(open(prefix + ".index", "rb").read())
+    raw[-1] ^= 0xff
+    open(prefix + ".index", "wb").write(bytes(raw))
+    with pytest.raises(ck.CheckpointFormatError, match="magic"):
+        ck.read_checkpoint(prefix)
