@@ -308,6 +308,28 @@ int mpg_semi_lagrange_bwd(mpg_stream_t stream, const float* dy, const float* vel
                           float vel_sign, float* dsource);
 int mpg_maccormack(mpg_stream_t stream, const float* source, const float* forward, const float* backward,
                    const float* flags, const float* vel, int n, int h, int w, float strength, float* out);
+/* ------------------------------------------------------------------------
+ * Training-tile supply on device-resident frames (tools_wscale/tilecreator_t.py).  The random
+ * decisions stay on the host (multi-pass-gan_amd/tiles_device.py); these are the array operations.
+ *   mpg_tile_gather: out[b] = frames[f][z0:z0+tz, y0:y0+ty, x0:x0+tx, c0:c0+c] with (f, c0, z0, y0, x0) = table[5 b ..]
+ *     (cutTile / getDatum, :403-450,562-574); frames [n_frames, z, y, x, cf], table in device memory.
+ *   mpg_resample_affine: scipy.ndimage.affine_transform / zoom with order 1, mode 'constant', cval 0 of a [zs,ys,xs,c]
+ *     array (:808-879): source coordinate = matrix9 * (z,y,x)_dst + offset3 in float64; channel_mix (c x c, or NULL)
+ *     is applied to the interpolated channels (vector components rotate / scale with the grid, :700-760,846-856).
+ *   mpg_tile_orient: crop [off, off + size) of src, axes permuted / reversed (the composed np.rot90 / np.flip of
+ *     :762-806), channels permuted / negated (chan_map, chan_sign: the vector components follow the turn).
+ *   mpg_semilagr_positions: getSemiLagrPosBatch (:1345-1378), 2D: vel [n_batch,h,w,3] (MAC, x,y,z), dt [n_batch] ->
+ *     pos [n_batch, n_out, n_out, 2] = (y, x) - v dt. */
+int mpg_tile_gather(mpg_stream_t stream, const float* frames, int n_frames, int z, int y, int x, int cf,
+                    const int* table, int n_tiles, int tz, int ty, int tx, int c, float* out);
+int mpg_resample_affine(mpg_stream_t stream, const float* src, int zs, int ys, int xs, int c, float* dst, int zd, int yd,
+                        int xd, const double* matrix9, const double* offset3, const float* channel_mix);
+int mpg_tile_orient(mpg_stream_t stream, const float* src, int zs, int ys, int xs, int c, const int* crop_off3,
+                    const int* crop_size3, const int* perm3, const int* flip3, const int* chan_map,
+                    const float* chan_sign, float* dst);
+int mpg_semilagr_positions(mpg_stream_t stream, const float* vel, const float* dt, int n_batch, int h, int w, int n_out,
+                           float* pos);
+
 /* the reductions of the generator losses (multipassGAN-4x.py:754,764-765): out[0] = sum |a - b| (mode 0,
  * tf.reduce_mean(tf.abs(..)) after division by n) or sum (a - b)^2 (mode 1, 2 * tf.nn.l2_loss); b NULL = 0 */
 int mpg_pair_reduce(mpg_stream_t stream, const float* a, const float* b, size_t n, int mode, float* out);

@@ -124,6 +124,12 @@ PROTOTYPES = {
     "mpg_semi_lagrange": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "mpg_semi_lagrange_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "mpg_maccormack": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mpg_tile_gather": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "mpg_resample_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)]),
+    "mpg_tile_orient": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I),
+                            ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_float), _P]),
+    "mpg_semilagr_positions": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mpg_pair_reduce": (_I, [_P, _P, _P, _Z, _I, _P]),
     "mpg_adam_step": (_I, [_P, _P, _P, _P, _P, _Z, _P, _F, _F, _F]),
     "mpg_adam_step_staged": (_I, [_P, _P, _P, _P, _P, _P, _Z, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _F]),

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I../../i
 build() {  # name, extra flags
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c mpgan_conv_mfma.hip -o $OUT/conv_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC mpgan_api.o $OUT/conv_$name.o mpgan_elem.o mpgan_train.o mpgan_wgrad_mfma.o -o $OUT/libmpgan_$name.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC mpgan_api.o $OUT/conv_$name.o mpgan_elem.o mpgan_train.o mpgan_wgrad_mfma.o mpgan_tiles.o -o $OUT/libmpgan_$name.so
   rm $OUT/conv_$name.o
 }
 for spec in "$@"; do
