@@ -49,6 +49,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_STAMPS
 #define MPG_STAMPS 0
 #endif
+//   MPG_DIAG 1 / 2 / 3: timing-only builds (results are garbage): 1 = no LDS fragment reads, 2 = no LDS-DMA pieces in the
+//                   stage loop, 3 = neither: what the MFMA issue structure alone costs
+#ifndef MPG_DIAG
+#define MPG_DIAG 0
+#endif
+
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
@@ -466,12 +472,20 @@ __device__ __forceinline__ unsigned lds_off(const void* p) {
 template <int OFF, class T>
 __device__ __forceinline__ void ds_read16(T& dst, unsigned addr) {
     static_assert(sizeof(T) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128");
+#if MPG_DIAG & 1
+    asm volatile("" : "=v"(dst) : "v"(addr));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
 }
 template <int OFF, class T>
 __device__ __forceinline__ void ds_read8(T& dst, unsigned addr) {
     static_assert(sizeof(T) == 8 && OFF >= 0 && OFF < 65536, "one ds_read_b64");
+#if MPG_DIAG & 1
+    asm volatile("" : "=v"(dst) : "v"(addr));
+#else
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
 }
 // wait until at most N of the LDS reads issued so far are outstanding (they return in order); tying the wait to the
 // fragment keeps every instruction that consumes it behind the wait
@@ -869,7 +883,8 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
                 static_for<0, G16>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                    if constexpr (g < HALF) {
+                    if constexpr ((MPG_DIAG & 2) != 0) {
+                    } else if constexpr (g < HALF) {
                         if (do_img)
                             static_for<0, IPG>([&](auto kc) {
                                 constexpr int i = g * IPG + decltype(kc)::value;

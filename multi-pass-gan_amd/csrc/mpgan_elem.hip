@@ -318,6 +318,35 @@ __global__ void cutoff_kernel(const float* __restrict__ v, size_t n, float cutof
     out[idx] = x < cutoff ? 0.f : x;
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+// 16 bytes per lane, streamed once (n4 = n / 4; the tail goes through cutoff_kernel)
+__global__ void cutoff4_kernel(const f4v* __restrict__ v, size_t n4, float cutoff, f4v* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n4) return;
+    f4v x = __builtin_nontemporal_load(v + idx);
+    x.x = x.x < cutoff ? 0.f : x.x; x.y = x.y < cutoff ? 0.f : x.y;
+    x.z = x.z < cutoff ? 0.f : x.z; x.w = x.w < cutoff ? 0.f : x.w;
+    __builtin_nontemporal_store(x, out + idx);
+}
+
+// transposes that keep the last axis (perm (1,0,2)) are row copies: out[i1][i0][:] = in[i0][i1][:], 16 bytes per lane
+__global__ void swap01_rows_kernel(const f4v* __restrict__ v, int d0, int d1, int row4, float cutoff, f4v* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)d0 * d1 * row4;
+    if (idx >= total) return;
+    const int q = idx % row4;
+    const size_t r = idx / row4;           // output row = i1 * d0 + i0
+    const int i0 = r % d0;
+    const int i1 = r / d0;
+    f4v x = __builtin_nontemporal_load(v + ((size_t)i0 * d1 + i1) * row4 + q);
+    if (cutoff > 0.f) {
+        x.x = x.x < cutoff ? 0.f : x.x; x.y = x.y < cutoff ? 0.f : x.y;
+        x.z = x.z < cutoff ? 0.f : x.z; x.w = x.w < cutoff ? 0.f : x.w;
+    }
+    __builtin_nontemporal_store(x, out + idx);
+}
+
 
 // tf.nn.conv2d_transpose(x, W[kh,kw,cout,cin], output_shape [n, h*sh, w*sw, cout], strides, "SAME") (GAN.py:703-708):
 // the gradient of the SAME convolution that maps the OUTPUT grid to the input grid, written as a gather.  Forward
@@ -509,6 +538,12 @@ extern "C" int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0,
         hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)nblk), dim3(BLK), 0, (hipStream_t)stream, v, t, out);
         MPG_LAUNCH_CHECK("transpose_tiled_kernel");
     }
+    if (c == 1 && ident_map && perm[0] == 1 && perm[1] == 0 && perm[2] == 2 && d2 % 4 == 0 && ((uintptr_t)v & 15) == 0 &&
+        ((uintptr_t)out & 15) == 0) {
+        hipLaunchKernelGGL(swap01_rows_kernel, dim3(grid_for(total / 4)), dim3(BLK), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f4v*>(v), d0, d1, d2 / 4, cutoff, reinterpret_cast<f4v*>(out));
+        MPG_LAUNCH_CHECK("swap01_rows_kernel");
+    }
     hipLaunchKernelGGL(transpose_generic_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, v, a, out);
     MPG_LAUNCH_CHECK("transpose_generic_kernel");
 }
@@ -527,6 +562,14 @@ extern "C" int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_tota
 extern "C" int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out) {
     MPG_REQUIRE(v && out, "mpg_cutoff: null pointer");
     if (n == 0) return MPG_OK;
+    if (n >= 1024 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+        const size_t n4 = n / 4;
+        hipLaunchKernelGGL(cutoff4_kernel, dim3(grid_for(n4)), dim3(BLK), 0, (hipStream_t)stream,
+                           reinterpret_cast<const f4v*>(v), n4, cutoff, reinterpret_cast<f4v*>(out));
+        if (n4 * 4 < n)
+            hipLaunchKernelGGL(cutoff_kernel, dim3(1), dim3(BLK), 0, (hipStream_t)stream, v + n4 * 4, n - n4 * 4, cutoff, out + n4 * 4);
+        MPG_LAUNCH_CHECK("cutoff4_kernel");
+    }
     hipLaunchKernelGGL(cutoff_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, v, n, cutoff, out);
     MPG_LAUNCH_CHECK("cutoff_kernel");
 }

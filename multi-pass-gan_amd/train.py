@@ -695,17 +695,22 @@ class StagedAdam(AdamTF):
             self.shadows = [self.flat.detach().clone() for _ in range(levels)]
         self._last_stage = None
 
-    def loss_scale(self, stage):
-        """2^ls_var as a device scalar (apply_loss_scaling, :506-507); 1 when loss scaling is off"""
-        if not self.loss_scaling:
-            return None
-        return torch.exp(self.state[stage][0] * math.log(2.0))
-
-    def step(self, grads, lr=None, stage=None):
+    def _enter(self, stage):
+        """the network has ONE ls_var (:501-503): when another stage's optimiser takes over, the value moves with it"""
         stage = self.levels - 1 if stage is None else int(stage)
         if self.loss_scaling and self._last_stage is not None and stage != self._last_stage:
-            self.state[stage][0] = self.state[self._last_stage][0]       # the network's single ls_var moves on with it
+            self.state[stage][0] = self.state[self._last_stage][0]
         self._last_stage = stage
+        return stage
+
+    def loss_scale(self, stage):
+        """2^ls_var as a device scalar (apply_loss_scaling, :506-507); None when loss scaling is off"""
+        if not self.loss_scaling:
+            return None
+        return torch.exp(self.state[self._enter(stage)][0] * math.log(2.0))
+
+    def step(self, grads, lr=None, stage=None):
+        stage = self._enter(stage)
         if lr is not None:
             self.lr = lr
         self.lr_dev.fill_(float(self.lr))
