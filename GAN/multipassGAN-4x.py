@@ -78,6 +78,13 @@ def train_main():
     if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
         print("ERROR: vorticity / flag / k-eps inputs and premade tiles are not supported")
         exit(1)
+    if int(P["pretrain"]) or int(P["pretrainDisc"]) or int(P["pretrainGen"]):
+        print("ERROR: the pretraining phases (pretrain / pretrainDisc / pretrainGen, 4x.py:1232-1296) are not built")
+        exit(1)
+    if int(P["genTestImg"]) > -1:
+        print("ERROR: PNG test images during training (genTestImg, 4x.py:1581-1600) are not built")
+        exit(1)
+    # `dropout` / `dropoutOutput` feed keep_prob, which no layer of the reference graph reads (4x.py:647-657)
     tileSizeLow, toSim = int(P["tileSize"]), int(P["toSim"])
     toSim = fromSim if toSim == -1 else toSim
     randSeed = int(P["randSeed"])
@@ -164,7 +171,8 @@ def train_main():
             for n_, t_ in trainer.sess.params.items():
                 if n_ in params:
                     t_.copy_(torch.as_tensor(params[n_], device=t_.device))
-        print("Model restored.")
+        n_slots = trainer.load_slot_state(params)                     # the Saver restores the Adam slots too (:961-975)
+        print("Model restored (%d variables with optimiser slots)." % n_slots)
     aug = int(P["dataAugmentation"]) > 0
     n_out = (tileSizeLow * upRes) ** 2
     n_in = (tileSizeLow * tileSizeLow if mode == 2 else n_out) * n_ch
@@ -173,18 +181,36 @@ def train_main():
         bx, by = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
         return bx.reshape(-1, n_in), by.reshape(-1, n_out)
 
+    keep_max, kept = int(P["keepMax"]), []
+
     def save(no):
         trainer.sess.sync_to_store()
-        checkpoint.save(test_path + 'model_%04d.ckpt' % no, trainer.sess.vars.numpy())
+        state = dict(trainer.sess.vars.numpy())
+        state.update(trainer.slot_state())
+        checkpoint.save(test_path + 'model_%04d.ckpt' % no, state)
+        kept.append(test_path + 'model_%04d.ckpt.npz' % no)
+        while keep_max > 0 and len(kept) > keep_max:                   # tf.train.Saver(max_to_keep=maxToKeep), :958
+            os.remove(kept.pop(0))
         print('Saved Model with number %d' % no)
 
     epochs = int(P["trainingEpochs"])
+    lr0, decay_lr = float(P["learningRate"]), int(P["decayLR"]) > 0
+    k_f, k2_f = float(P["lambda_f"]), float(P["lambda2_f"])
+
+    def decayed_lr(epoch):
+        """tf.train.polynomial_decay(lr, lrgs, epochs // 2, lr * 0.05, power=1.1) with lrgs = max(0, epoch - epochs // 2)
+        (4x.py:773-774,1304)"""
+        half = max(epochs // 2, 1)
+        step = min(max(0, epoch - epochs // 2), half)
+        return (lr0 - lr0 * 0.05) * (1.0 - step / float(half)) ** 1.1 + lr0 * 0.05
     discRuns, genRuns = int(P["discRuns"]), int(P["genRuns"])
     outputInterval, saveInterval = int(P["outputInterval"]), int(P["saveInterval"])
     save_no, t0 = 0, time.time()
     avg_d = avg_g = avg_l1 = 0.0
     print('\n*****TRAINING STARTED*****\n')
     for epoch in range(epochs):
+        if decay_lr:
+            trainer.set_learning_rate(decayed_lr(epoch))
         for _ in range(discRuns):
             bx, by = getinput()
             avg_d += float(trainer.disc_step(bx, by)["disc_loss"].detach())
@@ -195,6 +221,7 @@ def train_main():
                 trainer.tempo_disc_step(*tempo)
         for _ in range(genRuns):
             bx, by = getinput()
+            trainer.k, trainer.k2 = k_f * trainer.k, k2_f * trainer.k2   # :1342-1343
             if useTempoD:
                 tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
                 L = trainer.gen_step_tempo(bx, by, *tempo)

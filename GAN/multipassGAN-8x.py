@@ -267,7 +267,8 @@ if int(P["load_model_test"]) >= 0:
         for n_, t_ in trainer.sess.params.items():
             if n_ in params:
                 t_.copy_(torch.as_tensor(params[n_], device=t_.device))
-    print("Model restored.")
+    n_slots = trainer.load_slot_state(params)                         # the Saver restores the optimiser slots too
+    print("Model restored (%d optimiser slot pairs)." % n_slots)
 
 
 def getinput():
@@ -295,7 +296,9 @@ def saveModel():
     global save_no
     trainer.sess.sync_to_store()
     allp = trainer.sess.vars.numpy()
-    checkpoint.save(test_path + 'model_%04d.ckpt' % save_no, allp)
+    full = dict(allp)
+    full.update(trainer.slot_state())
+    checkpoint.save(test_path + 'model_%04d.ckpt' % save_no, full)
     ema = dict(allp)
     for n_, e_ in zip(trainer.opt_g.names, trainer.ema):           # MovingAverageOptimizer.swapping_saver (:1366)
         ema[n_] = e_.detach().cpu().numpy()

@@ -12,6 +12,8 @@ Fusion rules (all arithmetic stays in the kernels of libmpgan_hip.so):
     (addBicubicUpsample, multipassGAN-out.py:327-332).
 Everything else falls back to one kernel per node.
 """
+import re
+
 import numpy as np
 import torch
 
@@ -68,9 +70,13 @@ class VariableStore(object):
         self.values[name] = self._place(torch.as_tensor(np.ascontiguousarray(value), dtype=torch.float32))
         self.version += 1
 
+    _SLOT_KEY = re.compile(r"(^|/)(Adam(_\d+)?|beta[12]_power(_\d+)?|adam_t|ls_var|ExponentialMovingAverage)$")
+
     def load(self, params, prefix=""):
+        """model variables of a checkpoint; optimiser slots (TF Saver names) are the trainer's to restore"""
         for k, v in params.items():
-            self.set(prefix + k, v)
+            if not self._SLOT_KEY.search(k):
+                self.set(prefix + k, v)
 
     def numpy(self):
         return {k: v.cpu().numpy() for k, v in self.values.items()}

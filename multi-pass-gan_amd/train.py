@@ -11,6 +11,8 @@ with TensorFlow's epsilon placement.
 """
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib, ops, train_ops
@@ -645,6 +647,36 @@ class AdamTF(object):
             self.comm.all_reduce_mean(self.grad)
         train_ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr_t, self.b1, self.b2, self.eps)
 
+    def slot_state(self, tag):
+        """the optimiser's slots under the names tf.train.Saver gives them (``<variable>/Adam``, ``<variable>/Adam_1``;
+        the step count as TF's ``beta1_power`` = beta1^(t+1), prefixed with `tag` because every optimiser of a graph
+        owns one): what a checkpoint needs so that a resumed run continues like the reference's Saver restore"""
+        out, off = {}, 0
+        m, v = self.m.cpu().numpy(), self.v.cpu().numpy()
+        for n, p_ in zip(self.names, self.params):
+            k = p_.numel()
+            out[n + "/Adam"] = m[off:off + k].reshape(tuple(p_.shape))
+            out[n + "/Adam_1"] = v[off:off + k].reshape(tuple(p_.shape))
+            off += k
+        out[tag + "/beta1_power"] = np.float32(self.b1 ** (self.t + 1))
+        out[tag + "/adam_t"] = np.int64(self.t)
+        return out
+
+    def load_slot_state(self, state, tag):
+        """inverse of slot_state; variables without slots in `state` keep theirs.  Returns the number restored."""
+        off, hit = 0, 0
+        with torch.no_grad():
+            for n, p_ in zip(self.names, self.params):
+                k = p_.numel()
+                if n + "/Adam" in state and n + "/Adam_1" in state:
+                    self.m[off:off + k].copy_(torch.as_tensor(np.asarray(state[n + "/Adam"], np.float32).reshape(-1)))
+                    self.v[off:off + k].copy_(torch.as_tensor(np.asarray(state[n + "/Adam_1"], np.float32).reshape(-1)))
+                    hit += 1
+                off += k
+        if tag + "/adam_t" in state:
+            self.t = int(state[tag + "/adam_t"])
+        return hit
+
 
 def stage_variable_names(names, stage, levels):
     """the variables stage z of the growing schedule optimises (multipassGAN-8x.py:1316-1321,1331-1336,1347-1352): all of
@@ -725,6 +757,46 @@ class StagedAdam(AdamTF):
                                    self.LS_INC, self.LS_DEC, None if self.shadows is None else self.shadows[stage],
                                    self.ema_decay if self.ema_decay is not None else 0.0)
 
+    def slot_state(self, tag):
+        """every stage's moments (TF uniquifies the slot names of the z-th optimiser of a variable: ``Adam_<2z>`` /
+        ``Adam_<2z+1>``, the first pair without / with ``_1``), step counts and ls_var"""
+        out = {}
+        for z in range(self.levels):
+            m, v = self.ms[z].cpu().numpy(), self.vs[z].cpu().numpy()
+            chosen, off = set(stage_variable_names(self.names, z, self.levels)), 0
+            for n, p_ in zip(self.names, self.params):
+                k = p_.numel()
+                if n in chosen:
+                    out[n + self._slot(2 * z)] = m[off:off + k].reshape(tuple(p_.shape))
+                    out[n + self._slot(2 * z + 1)] = v[off:off + k].reshape(tuple(p_.shape))
+                off += k
+            st = self.state[z].cpu().numpy()
+            out["%s/stage%d/adam_t" % (tag, z)] = np.int64(st[3])
+            out["%s/stage%d/ls_var" % (tag, z)] = np.float32(st[0])
+        return out
+
+    @staticmethod
+    def _slot(i):
+        return "/Adam" if i == 0 else "/Adam_%d" % i
+
+    def load_slot_state(self, state, tag):
+        hit = 0
+        with torch.no_grad():
+            for z in range(self.levels):
+                off = 0
+                for n, p_ in zip(self.names, self.params):
+                    k = p_.numel()
+                    km, kv = n + self._slot(2 * z), n + self._slot(2 * z + 1)
+                    if km in state and kv in state:
+                        self.ms[z][off:off + k].copy_(torch.as_tensor(np.asarray(state[km], np.float32).reshape(-1)))
+                        self.vs[z][off:off + k].copy_(torch.as_tensor(np.asarray(state[kv], np.float32).reshape(-1)))
+                        hit += 1
+                    off += k
+                if "%s/stage%d/adam_t" % (tag, z) in state:
+                    self.state[z][3] = float(state["%s/stage%d/adam_t" % (tag, z)])
+                    self.state[z][0] = float(state["%s/stage%d/ls_var" % (tag, z)])
+        return hit
+
     def ema_params(self, stage=None):
         """name -> moving-average tensor of the stage's shadows (swapping_saver of the last stage's optimiser, :1369)"""
         stage = self.levels - 1 if stage is None else stage
@@ -790,6 +862,24 @@ class Trainer4x(object):
         if use_tempo:
             self.t_var = {n: p for n, p in self.sess.trainable("t_").items() if n.startswith("discriminatorTempo")}
             self.opt_t = AdamTF(self.t_var, learning_rate, beta1, comm=comm)
+
+    def optimisers(self):
+        """-> [(tag, AdamTF)] in the order the reference creates them (:812-900)"""
+        return [("disc", self.opt_d), ("gen", self.opt_g)] + ([("tempo", self.opt_t)] if hasattr(self, "opt_t") else [])
+
+    def set_learning_rate(self, lr):
+        """the fed learning rate of all optimisers (the decayLR schedule of :773-774 is evaluated by the caller)"""
+        for _, o in self.optimisers():
+            o.lr = float(lr)
+
+    def slot_state(self):
+        out = {}
+        for tag, o in self.optimisers():
+            out.update(o.slot_state(tag))
+        return out
+
+    def load_slot_state(self, state):
+        return sum(o.load_slot_state(state, tag) for tag, o in self.optimisers())
 
     def losses(self, batch_xs, batch_ys):
         """-> dict of the loss tensors of multipassGAN-4x.py:744-768 (one forward of G, D(real), D(fake))"""
@@ -1105,6 +1195,18 @@ class Trainer8x(object):
         L["t_disc_loss"] = t_disc_loss
         L["g_loss_t"] = self._adv(gen_s, True)
         return L
+
+    def optimisers(self):
+        return [("disc", self.opt_d), ("gen", self.opt_g)] + ([("tempo", self.opt_t)] if hasattr(self, "opt_t") else [])
+
+    def slot_state(self):
+        out = {}
+        for tag, o in self.optimisers():
+            out.update(o.slot_state(tag))
+        return out
+
+    def load_slot_state(self, state):
+        return sum(o.load_slot_state(state, tag) for tag, o in self.optimisers())
 
     @property
     def ema(self):
