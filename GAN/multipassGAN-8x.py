@@ -15,7 +15,7 @@ checkpoints ``model_%04d.ckpt.npz`` and the moving-average weights ``model_ema_%
 
 ``out 1`` is the per-network output mode (see output_main).
 
-Not rebuilt: upsamplingMode 0 (the linear-interpolation variant no example run uses), adv_mode 1 / 2 in the training loop (the GAN.advect kernels exist: train_ops.advect), vorticity / flag / k-eps
+Not rebuilt: upsamplingMode 0 (the linear-interpolation variant no example run uses), vorticity / flag / k-eps
 inputs, PNG test images, TensorBoard.  ``lossScaling 1`` runs the dynamic loss scaling of :490-541 and every
 stage uses its own optimisers over its own variable subset (:1305-1362) -- train.StagedAdam.
 """
@@ -162,8 +162,8 @@ kt, kt_l = float(P["lambda_t"]), float(P["lambda_t_l2"])
 useTempoD = kt > 1e-6                                                # 8x.py:191-199
 if kt_l > 1e-6:
     fail("the l2 temporal loss (lambda_t_l2) is not built; use lambda_t")
-if useTempoD and int(P["adv_flag"]) and int(P["adv_mode"]):
-    fail("adv_mode 1 / 2 (GAN.advect) is not built; use adv_mode 0 (tensorResample)")
+if useTempoD and int(P["adv_flag"]) and int(P["adv_mode"]) and not int(P["useVelocities"]):
+    fail("adv_mode 1 / 2 (GAN.advect) advects with the velocity channels of the low-res tiles: useVelocities 1")
 
 basePath, packedSimPath = P["basePath"], P["packedSimPath"]
 simSizeLow, tileSizeLow = int(P["simSize"]), int(P["tileSize"])
@@ -260,7 +260,8 @@ trainer = Trainer8x(cfg, device=device, learning_rate=learning_rate, beta1=float
                     beta2=float(P["adam_beta2"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
                     weight_dld=float(P["weight_dld"]), use_wgan_gp=int(P["use_wgan_gp"]) > 0,
                     use_LSGAN=int(P["use_LSGAN"]) > 0, seed=randSeed, use_tempo=useTempoD, lambda_t=kt,
-                    adv_flag=int(P["adv_flag"]) > 0, loss_scaling=int(P["lossScaling"]) > 0)
+                    adv_flag=int(P["adv_flag"]) > 0, loss_scaling=int(P["lossScaling"]) > 0,
+                    adv_mode=int(P["adv_mode"]))
 if int(P["load_model_test"]) >= 0:
     params = checkpoint.load(checkpoint.model_path(basePath, int(P["load_model_test"]), int(P["load_model_no"])))
     with torch.no_grad():

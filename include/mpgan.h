@@ -299,7 +299,9 @@ int mpg_adam_step_staged(mpg_stream_t stream, float* p, const float* grad, float
  *     _bwd: gradient with respect to source (dsource is overwritten).
  *   mpg_maccormack (one channel): the MacCormack correction forward + strength/2 (source - backward) where
  *     flags < 0.2, clamped back to `forward` where it leaves the [min, max] of the fluid cells around the truncated
- *     look-up position (:206-343, index clipping as written there; n <= w). */
+ *     look-up position (:206-343, index clipping as written there: for three of the four corners the batch index is
+ *     clipped to w-1 too).  keep (may be NULL) receives 1 where the correction term survived: the only place where
+ *     d out / d source differs from the semi-Lagrangian one (TensorFlow differentiates tf.where by its branches). */
 int mpg_advect_velocity(mpg_stream_t stream, const float* vel, int n, int hv, int wv, int cv, int h, int w, float dt,
                         float* out);
 int mpg_semi_lagrange(mpg_stream_t stream, const float* source, const float* vel, int n, int h, int w, int c,
@@ -307,7 +309,7 @@ int mpg_semi_lagrange(mpg_stream_t stream, const float* source, const float* vel
 int mpg_semi_lagrange_bwd(mpg_stream_t stream, const float* dy, const float* vel, int n, int h, int w, int c,
                           float vel_sign, float* dsource);
 int mpg_maccormack(mpg_stream_t stream, const float* source, const float* forward, const float* backward,
-                   const float* flags, const float* vel, int n, int h, int w, float strength, float* out);
+                   const float* flags, const float* vel, int n, int h, int w, float strength, float* out, float* keep);
 /* ------------------------------------------------------------------------
  * Training-tile supply on device-resident frames (tools_wscale/tilecreator_t.py).  The random
  * decisions stay on the host (multi-pass-gan_amd/tiles_device.py); these are the array operations.

@@ -217,6 +217,10 @@ class GAN(object):
                 self.layer = activation_function(self.layer)
             return self.layer, layer_lin
 
+    # GAN.py:347-418: semi-Lagrangian (order 1) / MacCormack (order 2) advection of `source` by the velocity tile
+    def advect(self, source, vel, flags, dt, order, strength=0.0, name="Advection", startBz=15):
+        return G.advect(source, vel, flags, dt, order, strength, startBz)
+
     # GAN.py:624-631
     def noise(self, channels=-1):
         raise NotImplementedError("noise layers are not used by the multi-pass generators")

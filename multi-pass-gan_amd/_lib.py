@@ -123,7 +123,7 @@ PROTOTYPES = {
     "mpg_advect_velocity": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_semi_lagrange": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "mpg_semi_lagrange_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
-    "mpg_maccormack": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mpg_maccormack": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     "mpg_tile_gather": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "mpg_resample_affine": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float)]),

@@ -568,7 +568,7 @@ __global__ void semi_lagrange_bwd_kernel(const float* __restrict__ dy, const flo
 // writes it: the first corner is clipped per axis (h-1, w-1), the other three -- batch index included -- to w-1.
 __global__ void maccormack_kernel(const float* __restrict__ src, const float* __restrict__ fwd, const float* __restrict__ bwd,
                                   const float* __restrict__ flags, const float* __restrict__ vel, int n, int h, int w,
-                                  float strength, float* __restrict__ out) {
+                                  float strength, float* __restrict__ out, float* __restrict__ keep) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
     const size_t total = (size_t)n * h * w;
     if (idx >= total) return;
@@ -576,7 +576,8 @@ __global__ void maccormack_kernel(const float* __restrict__ src, const float* __
     const int i = (idx / w) % h;
     const int b = idx / ((size_t)w * h);
     const float f = fwd[idx];
-    const float corr = flags[idx] < 0.2f ? f + strength * 0.5f * (src[idx] - bwd[idx]) : f;
+    const bool fluid = flags[idx] < 0.2f;
+    const float corr = fluid ? f + strength * 0.5f * (src[idx] - bwd[idx]) : f;
     const int cy = (int)(((float)i + 1.0f) - vel[idx * 2]), cx = (int)(((float)j + 1.0f) - vel[idx * 2 + 1]);   // truncation
     const int i0 = min(max(cy, 0), h - 1), j0 = min(max(cx, 0), w - 1);
     const float big = 9223372036854775807.0f;
@@ -596,6 +597,7 @@ __global__ void maccormack_kernel(const float* __restrict__ src, const float* __
     }
     const bool reject = corr < lo || corr > hi || lo == lo_i || hi == hi_i;
     out[idx] = reject ? f : corr;
+    if (keep != nullptr) keep[idx] = (!reject && fluid) ? 1.f : 0.f;   // where the correction term carries gradient
 }
 
 
@@ -898,12 +900,12 @@ extern "C" int mpg_semi_lagrange_bwd(mpg_stream_t stream, const float* dy, const
 }
 
 extern "C" int mpg_maccormack(mpg_stream_t stream, const float* source, const float* forward, const float* backward,
-                              const float* flags, const float* vel, int n, int h, int w, float strength, float* out) {
+                              const float* flags, const float* vel, int n, int h, int w, float strength, float* out,
+                              float* keep) {
     MPG_REQUIRE(source && forward && backward && flags && vel && out, "mpg_maccormack: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1, "mpg_maccormack: bad shape");
-    MPG_REQUIRE(n <= w, "mpg_maccormack: batch %d exceeds the field width %d (the reference clips the batch index to it)", n, w);
     const size_t total = (size_t)n * h * w;
     hipLaunchKernelGGL(maccormack_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, source, forward, backward,
-                       flags, vel, n, h, w, strength, out);
+                       flags, vel, n, h, w, strength, out, keep);
     MPG_LAUNCH_CHECK("maccormack_kernel");
 }

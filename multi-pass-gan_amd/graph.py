@@ -243,6 +243,17 @@ def minibatch_stddev(x, group_size=4):
     return Node("minibatch_stddev", [x], shape=(x.shape[0], x.shape[1], x.shape[2], x.shape[3] + 1), group_size=int(group_size))
 
 
+def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
+    """GAN.advect (GAN.py:347-418): `source` [n,h,w,c] carried by the (MAC) velocity channels (x, y) of `vel`
+    [n,hv,wv,>=2] over dt * (+1, 0, -1) per frame triple; order 1 semi-Lagrangian, order 2 MacCormack (`flags`: cells
+    below 0.2 are fluid)"""
+    if len(source.shape) != 4 or len(vel.shape) != 4 or vel.shape[3] < 2:
+        raise GraphError("advect: source %s / velocity %s" % (source.shape, vel.shape))
+    ins = [source, vel] + ([flags] if flags is not None else [])
+    return Node("advect", ins, shape=source.shape, dt=float(dt), order=int(order), strength=float(strength),
+                start_bz=int(start_bz))
+
+
 def resize_images(x, size, method=0):
     """tf.image.resize_images(x, [oh, ow], method) with TF1 legacy coordinates."""
     oh, ow = int(size[0]), int(size[1])

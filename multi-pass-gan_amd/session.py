@@ -554,6 +554,16 @@ class Session(object):
         if op == "depth_to_space":
             x = n.inputs[0]
             return [x], lambda env: ops.depth_to_space(self._f32(env, x), n.attrs["r"])
+        if op == "advect":
+            from . import train_ops
+
+            def run_advect(env, n=n):
+                src, vel = self._f32(env, n.inputs[0]), self._f32(env, n.inputs[1])
+                flags = self._f32(env, n.inputs[2]) if len(n.inputs) > 2 else torch.zeros_like(src[..., :1])
+                at = n.attrs
+                return train_ops.advect(src, vel, flags, at["dt"], at["order"], at["strength"], at["start_bz"])
+
+            return list(n.inputs), run_advect
         if op in ("conv2d", "conv2d_transpose", "bias_add", "batch_norm"):
             direct = self._match_direct(n, single_use)
             if direct is not None:

@@ -547,6 +547,11 @@ class TrainSession(object):
             x = None if n.attrs["zero_x"] else ev(n.inputs[0])
             y = ev(n.inputs[-1])
             return (Lerp2Fn if self._higher(n) else LerpFn).apply(x, y, t)
+        if op == "advect":
+            src, vel = ev(n.inputs[0]), ev(n.inputs[1])
+            flags = ev(n.inputs[2]) if len(n.inputs) > 2 else torch.zeros_like(src[..., :1])
+            at = n.attrs
+            return train_ops.advect(src, vel.detach(), flags.detach(), at["dt"], at["order"], at["strength"], at["start_bz"])
         if op == "minibatch_stddev":
             x = ev(n.inputs[0])
             if x.requires_grad:
@@ -1018,7 +1023,7 @@ class Trainer8x(object):
     def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
                  prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999, use_tempo=False, lambda_t=1.0,
-                 adv_flag=True, clamping=True, loss_scaling=False):
+                 adv_flag=True, clamping=True, loss_scaling=False, adv_mode=0):
         from . import arch
         from .session import VariableStore
         self.cfg = cfg
@@ -1048,6 +1053,12 @@ class Trainer8x(object):
         self.k2_ls = list(k2_ls) if k2_ls is not None else [1.0] * len(self.f_y)
         # temporal discriminator (multipassGAN-8x.py:1158-1300; final growing stage, tensorResample advection)
         self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
+        # 0: tensorResample on positions computed by the tile creator; 1 / 2: GAN.advect on the low-res velocity channels
+        # of x_t, semi-Lagrangian / MacCormack (:1193-1199,1221-1225)
+        self.adv_mode = int(adv_mode)
+        if use_tempo and adv_flag and self.adv_mode and cfg.n_inputChannels != 4:
+            raise _lib.MpgError("adv_mode %d reads the velocity from channels 1..3 of a 4-channel low-res tile (:1187), "
+                                "got %d channels" % (self.adv_mode, cfg.n_inputChannels))
         if use_tempo:
             self.x_t = G.placeholder([None, cfg.n_input], name="x_t")
             if cfg.upsampling_mode == 2:
@@ -1143,20 +1154,30 @@ class Trainer8x(object):
         return ops.resize_nearest(ys.reshape(-1, cur, cur, 1).contiguous(), th, th).reshape(-1, th * th)
 
     # ------------------------------------------------------------------ temporal branch
-    def _frames_as_channels(self, frames, y_pos):
+    def _frames_as_channels(self, frames, y_pos, xts=None, percentage=3.0):
         """advection look-up at the CURRENT stage's resolution (the positions come at tileSizeLow * 2^stage):
         generated frames are nearest-downsampled to it, resampled, and resized back (:1178-1200)"""
         th = self.cfg.tileSizeHigh
         frames = frames.reshape(frames.shape[0], -1)
         cur = int(round(math.sqrt(frames.shape[1])))
         if self.adv_flag:
-            pos = torch.as_tensor(y_pos, dtype=torch.float32, device=frames.device)
-            pc = int(round(math.sqrt(pos.shape[1] // 2)))
+            if self.adv_mode:
+                tl = self.cfg.tileSizeLow
+                pc = tl * 2 ** int(math.ceil(percentage)) if self.cfg.upsampling_mode == 2 else th   # currentTileSizeX
+                pos = None
+            else:
+                pos = torch.as_tensor(y_pos, dtype=torch.float32, device=frames.device)
+                pc = int(round(math.sqrt(pos.shape[1] // 2)))
             v = frames.reshape(-1, cur, cur, 1)
             if cur != pc:                                   # generator output (full size) -> current size
                 k = cur // pc
                 v = v[:, ::k, ::k, :].contiguous()
-            v = ResampleFn.apply(v, pos.reshape(-1, pc, pc, 2), self.clamping)
+            if pos is None:
+                vel_t = xts.reshape(-1, tl, tl, 4)[..., 1:4].contiguous()
+                n = v.shape[0]                              # startBz = (batch // 3) * 3 = the rows of a tempo batch
+                v = train_ops.advect(v, vel_t, torch.zeros_like(v), 0.5, self.adv_mode, 1.0, start_bz=n)
+            else:
+                v = ResampleFn.apply(v, pos.reshape(-1, pc, pc, 2), self.clamping)
             if pc != th:
                 v = (ResizeNearest2Fn if self.use_wgan_gp else ResizeNearestFn).apply(v, th, th)
         else:
@@ -1173,8 +1194,8 @@ class Trainer8x(object):
         else:       # rows of (target, previous pass) pairs: the real frames are channel 0 (:1218-1219)
             gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.y_t2: yts, self.percentage: percentage})[0]
             yts = yts.reshape(-1, self.cfg.n_output, 2)[:, :, 0].contiguous()
-        fake = self._frames_as_channels(gen_ts, batch_y_pos)
-        real = self._frames_as_channels(yts, batch_y_pos)
+        fake = self._frames_as_channels(gen_ts, batch_y_pos, xts, percentage)
+        real = self._frames_as_channels(yts, batch_y_pos, xts, percentage)
         gen_s, disc_s = self.sess.run([self.gen_s, self.disc_s], {self.t_fake: fake, self.t_real: real,
                                                                    self.percentage: percentage})
         L = {"t_loss_y": self._adv(disc_s, True), "t_loss_g": self._adv(gen_s, False)}

@@ -240,26 +240,48 @@ class _SemiLagrangeFn(torch.autograd.Function):
         return semi_lagrange_bwd(dy.contiguous(), vel_c, ctx.sign), None, None
 
 
+class _MacCormackFn(torch.autograd.Function):
+    """order 2 of GAN.advect on one channel.  TensorFlow differentiates the op graph of GAN.py:206-343 branch by branch:
+    the min / max clamp and the flag test only select, so with keep = (correction survived)
+        out = fwd + keep * strength/2 * (source - bwd),  fwd = SL(source, +v),  bwd = SL(fwd, -v)
+    and d source = g + SL^T(+v)[dy - SL^T(-v)[g]] with g = keep * strength/2 * dy."""
+
+    @staticmethod
+    def forward(ctx, source, vel_c, flags, strength):
+        lib = _lib.load()
+        n, h, w, _ = source.shape
+        src = _cont(source, "source")
+        fwd = semi_lagrange(src, vel_c, 1.0)
+        bwd = semi_lagrange(fwd, vel_c, -1.0)
+        out, keep = torch.empty_like(src), torch.empty_like(src)
+        _lib.check(lib.mpg_maccormack(_stream(), _ptr(src), _ptr(fwd), _ptr(bwd), _ptr(flags), _ptr(vel_c), n, h, w,
+                                      float(strength), _ptr(out), _ptr(keep)), "mpg_maccormack")
+        ctx.save_for_backward(vel_c, keep)
+        ctx.strength = float(strength)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        vel_c, keep = ctx.saved_tensors
+        g = keep * (0.5 * ctx.strength) * dy
+        d_fwd = dy - semi_lagrange_bwd(g, vel_c, -1.0)
+        return g + semi_lagrange_bwd(d_fwd, vel_c, 1.0), None, None, None
+
+
 def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
-    """GAN.advect (GAN.py:347-418) on [n,h,w,c] device tensors (h == w, n a multiple of 3).  order 1: semi-Lagrangian
-    (differentiable in source); order 2: MacCormack with the reference's clamp (one channel, forward only)."""
+    """GAN.advect (GAN.py:347-418) on [n,h,w,c] device tensors (h == w, n a multiple of 3), differentiable in source.
+    order 1: semi-Lagrangian; order 2: MacCormack with the reference's clamp (one channel; `start_bz` must be the
+    batch size, as the reference's tf.where requires)."""
     n, h, w, c = source.shape
     if h != w:
         raise _lib.MpgError("advect: the reference's position grid is only a mesh for square fields (GAN.py:362-374)")
     vel_c = advect_velocity(vel, h, w, dt)
-    fwd = _SemiLagrangeFn.apply(source, vel_c, 1.0)
     if order != 2:
-        return fwd
+        return _SemiLagrangeFn.apply(source, vel_c, 1.0)
     if c != 1 or start_bz != n:
         raise _lib.MpgError("advect order 2: one channel and startBz == batch size (tf.where in GAN.py:343 needs both)")
-    lib = _lib.load()
-    src, f = _cont(source.detach(), "source"), _cont(fwd.detach(), "forward")
-    bwd = semi_lagrange(f, vel_c, -1.0)
-    flags = _cont(flags.reshape(n, h, w, 1), "flags")
-    out = torch.empty_like(src)
-    _lib.check(lib.mpg_maccormack(_stream(), _ptr(src), _ptr(f), _ptr(bwd), _ptr(flags), _ptr(vel_c), n, h, w, float(strength),
-                                  _ptr(out)), "mpg_maccormack")
-    return out
+    flags = _cont(flags.reshape(n, h, w, 1).to(torch.float32), "flags")
+    return _MacCormackFn.apply(source, vel_c, flags, float(strength))
 
 
 def pair_reduce(a, b, mode):

@@ -96,27 +96,8 @@ def maccormack_correct(flags, source, forward, backward, strength=1.0):
 def maccormack_clamp(flags, vel, intermed, source, forward, pos, start_bz):
     """doClampComponent (:213-343): the corrected value is kept only inside the [min, max] of the (fluid) cells around the
     truncated look-up position; channel 0 of `source` / `flags` is what the reference gathers."""
-    n, h, w, _ = source.shape
-    assert start_bz == n, "the reference's tf.where needs startBz == batch size"
-    cur = np.trunc(np.broadcast_to(pos, vel.shape).astype(F32) - vel).astype(np.int32)     # tf.cast(float -> int32)
-    i0 = np.clip(cur[..., 0], 0, h - 1)
-    j0 = np.clip(cur[..., 1], 0, w - 1)
-    b = np.broadcast_to(np.arange(n)[:, None, None], i0.shape)
-    lo = np.full(source.shape[:3] + (1,), BIG, dtype=F32)
-    hi = np.full(source.shape[:3] + (1,), -BIG - 1, dtype=F32)
-    lo_i, hi_i = lo.copy(), hi.copy()
-    top = w - 1                                         # every index component is clipped to grid_res[2] - 1 (:270-272)
-    for di, dj in ((0, 0), (1, 0), (0, 1), (1, 1)):
-        if (di, dj) == (0, 0):
-            bb, ii, jj = b, i0, j0                      # indices_0 is not clipped again (:269)
-        else:
-            bb, ii, jj = np.clip(b, 0, top), np.clip(i0 + di, 0, top), np.clip(j0 + dj, 0, top)
-        s = source[bb, ii, jj, 0][..., None]
-        fluid = flags[bb, ii, jj, 0][..., None] < F32(THRESHOLD_FLAGS)
-        lo = np.where(fluid, np.minimum(lo, s), lo)
-        hi = np.where(fluid, np.maximum(hi, s), hi)
-    reject = (intermed < lo) | (intermed > hi) | (lo == lo_i) | (hi == hi_i)
-    return np.where(reject, forward, intermed).astype(F32)
+    assert start_bz == source.shape[0], "the reference's tf.where needs startBz == batch size"
+    return np.where(_rejected(flags, vel, intermed, source, pos), forward, intermed).astype(F32)
 
 
 def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
@@ -132,3 +113,67 @@ def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
     flags = np.asarray(flags, dtype=F32).reshape(n, h, w, 1)
     corrected = maccormack_correct(flags, source, forward, backward, strength)
     return maccormack_clamp(flags, v, corrected, source, forward, pos, start_bz)
+
+
+def advect_torch(source, vel, flags, dt, order, strength=0.0, start_bz=15):
+    """GAN.advect as a differentiable float64 torch expression in `source` (a torch tensor [N,H,W,C]); velocities and
+    flags are data.  Index / weight arithmetic in float32 exactly as in `semi_lagrange`; the gathers, the correction and
+    the tf.where selections are torch ops, so autograd yields what TensorFlow's gradient of the op graph yields
+    (selections pass the gradient of the chosen branch; comparisons carry none)."""
+    import torch
+    n, h, w, c = source.shape
+    pos = positions(h, w)
+    v = centred_velocity(np.asarray(vel, dtype=F32), h, w, dt)
+
+    def sl(src, vv):
+        p = (pos.astype(F32) - vv).astype(F32)
+        q = p - F32(0.5)
+        lo = np.floor(q).astype(np.int64)
+        hi = lo + 1
+        lim = np.array([h - 1, w - 1], dtype=np.int64)
+        lo = np.minimum(np.maximum(lo, 0), lim)
+        hi = np.minimum(np.maximum(hi, 0), lim)
+        b = torch.arange(n).reshape(n, 1, 1)
+        out = 0
+        for corner in range(4):
+            use_hi = np.array([bool(corner & 1), bool(corner & 2)])
+            idx = np.where(use_hi, hi, lo)
+            wgt = np.prod(F32(1.0) - np.abs(q - idx.astype(F32)), axis=-1, keepdims=True, dtype=F32)
+            out = out + src[b, torch.as_tensor(idx[..., 0]), torch.as_tensor(idx[..., 1]), :] * torch.as_tensor(wgt.astype(np.float64))
+        return out
+
+    forward = sl(source, v)
+    if order != 2:
+        return forward
+    backward = sl(forward, -v)
+    flags = np.asarray(flags, dtype=F32).reshape(n, h, w, 1)
+    fluid = torch.as_tensor(flags < F32(THRESHOLD_FLAGS))
+    corrected = torch.where(fluid, forward + strength * 0.5 * (source - backward), forward)
+    # the clamp decides on float32 values, as the graph does
+    f32 = lambda t: t.detach().numpy().astype(F32)                    # noqa: E731
+    assert start_bz == n, "the reference's tf.where needs startBz == batch size"
+    reject = torch.as_tensor(_rejected(flags, v, f32(corrected), f32(source), pos))
+    return torch.where(reject, forward, corrected)
+
+
+def _rejected(flags, vel, intermed, source, pos):
+    """cond_complete of doClampComponent (:269-343)"""
+    n, h, w, _ = source.shape
+    cur = np.trunc(np.broadcast_to(pos, vel.shape).astype(F32) - vel).astype(np.int32)
+    i0 = np.clip(cur[..., 0], 0, h - 1)
+    j0 = np.clip(cur[..., 1], 0, w - 1)
+    b = np.broadcast_to(np.arange(n)[:, None, None], i0.shape)
+    lo = np.full(source.shape[:3] + (1,), BIG, dtype=F32)
+    hi = np.full(source.shape[:3] + (1,), -BIG - 1, dtype=F32)
+    lo_i, hi_i = lo.copy(), hi.copy()
+    top = w - 1                                         # every index component is clipped to grid_res[2] - 1 (:270-272)
+    for di, dj in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        if (di, dj) == (0, 0):
+            bb, ii, jj = b, i0, j0                      # indices_0 is not clipped again (:269)
+        else:
+            bb, ii, jj = np.clip(b, 0, top), np.clip(i0 + di, 0, top), np.clip(j0 + dj, 0, top)
+        s = source[bb, ii, jj, 0][..., None]
+        fl = flags[bb, ii, jj, 0][..., None] < F32(THRESHOLD_FLAGS)
+        lo = np.where(fl, np.minimum(lo, s), lo)
+        hi = np.where(fl, np.maximum(hi, s), hi)
+    return (intermed < lo) | (intermed > hi) | (lo == lo_i) | (hi == hi_i)

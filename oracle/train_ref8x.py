@@ -132,15 +132,22 @@ def growing_disc_tempo(p, x_nchw, percentage, up_res=8, current_upres=3):
 
 
 def tempo_losses_8x(p, batch_xts, batch_yts, batch_y_pos, tile_low, channels, percentage=3.0, lerp_factor=None,
-                    wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True):
-    """t_disc_loss / g_loss_t (WGAN-GP) of multipassGAN-8x.py:1216-1300 at the final stage"""
+                    wgan_lambda=10.0, wgan_target=1.0, wgan_epsilon=1e-3, weight_dld=1.0, first_nn_arch=True, adv_mode=0):
+    """t_disc_loss / g_loss_t (WGAN-GP) of multipassGAN-8x.py:1216-1300 at the final stage; adv_mode 0 looks the frames
+    up at the fed positions (tensorResample), 1 / 2 advects them with GAN.advect on the velocity channels of x_t
+    (:1193-1199,1221-1225)"""
     from .train_ref import tensor_resample
+    from . import advect as ADV
     th = tile_low * 8
     xs = np.asarray(batch_xts, np.float32).reshape(-1, tile_low, tile_low, channels)
     gen_ts = growing_gen(p, xs, percentage, first_nn_arch)                 # [3B,1,H,W]
 
     def pack(frames_nhwc):
-        v = tensor_resample(frames_nhwc, batch_y_pos, True)
+        if adv_mode:
+            n = frames_nhwc.shape[0]
+            v = ADV.advect_torch(frames_nhwc, xs[..., 1:4], np.zeros((n, th, th, 1), np.float32), 0.5, adv_mode, 1.0, n)
+        else:
+            v = tensor_resample(frames_nhwc, batch_y_pos, True)
         return v.reshape(-1, 3, th * th).permute(0, 2, 1)                  # [B, n_output, 3]
 
     fake = pack(gen_ts.permute(0, 2, 3, 1))

@@ -109,8 +109,10 @@ def test_lsgan_variant_losses():
     assert abs(float(L["disc_loss"].detach()) - float(want)) < 2e-4 * max(abs(float(want)), 1e-2)
 
 
-def test_temporal_critic_losses_and_gradients():
-    """growing_disc_tempo on advected frame triples with its own gradient penalty; generator term"""
+@pytest.mark.parametrize("adv_mode", [0, 1, 2])
+def test_temporal_critic_losses_and_gradients(adv_mode):
+    """growing_disc_tempo on advected frame triples with its own gradient penalty; generator term.  adv_mode 0:
+    tensorResample at the tile creator's positions; 1 / 2: GAN.advect (semi-Lagrange / MacCormack) inside the step"""
     import contextlib
     import io
     import random
@@ -123,10 +125,10 @@ def test_temporal_critic_losses_and_gradients():
         tiCr.addData(rng.random((4, 1, 16, 16, 12)).astype(np.float32), rng.random((4, 1, 128, 128, 3)).astype(np.float32))
     random.seed(2)
     xts, yts, ypos = tiCr.selectRandomTempoTiles(6, True, False, n_t=3, dt=0.5)
-    tr, p, xs, ys, lf = make(tile=tile, C=C, batch=2, use_tempo=True)
+    tr, p, xs, ys, lf = make(tile=tile, C=C, batch=2, use_tempo=True, adv_mode=adv_mode)
     lf_t = rng.random((2, 1)).astype(np.float32)
     L = tr.tempo_losses(xts, yts, ypos, 3.0, lf_t)
-    Lr = TR8.tempo_losses_8x(p, xts, yts, ypos, tile, C, 3.0, lf_t)
+    Lr = TR8.tempo_losses_8x(p, xts, yts, ypos, tile, C, 3.0, lf_t, adv_mode=adv_mode)
     for k in ("t_disc_loss", "g_loss_t"):
         a, b = float(L[k].detach()), float(Lr[k].detach())
         assert abs(a - b) <= 2e-4 * max(abs(b), 1e-2), (k, a, b)

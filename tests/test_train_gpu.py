@@ -455,3 +455,61 @@ def test_advect_kernels_vs_oracle(hv):
     lhs = float((out.detach().cpu().double() * g.cpu().double()).sum())
     rhs = float((s2 * ds.cpu().double()).sum())
     assert abs(lhs - rhs) < 1e-3 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.parametrize("order,n,h", [(1, 6, 16), (2, 6, 16), (2, 24, 16)])
+def test_advect_gradient_vs_torch_restatement(order, n, h):
+    """d advect / d source for both orders against autograd on the float64 restatement of the op graph; the last case has
+    more batch rows than columns (the reference clips the batch index of three clamp corners to w-1)"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import train_ops
+    from oracle import advect as A
+    rng = np.random.default_rng(100 * order + n)
+    src = rng.random((n, h, h, 1)).astype(np.float32)
+    src[:, :5] = 0.0                                      # empty region: forward == corrected there, the mask still counts
+    vel = (rng.standard_normal((n, 8, 8, 3)) * 2.0).astype(np.float32)
+    flags = (rng.random((n, h, h, 1)) < 0.2).astype(np.float32)
+    g = rng.standard_normal((n, h, h, 1))
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    s = t(src).requires_grad_(True)
+    out = train_ops.advect(s, t(vel), t(flags), 0.5, order, 1.0, start_bz=n)
+    (ds,) = torch.autograd.grad(out, [s], t(g.astype(np.float32)))
+    s64 = torch.tensor(src, dtype=torch.float64, requires_grad=True)
+    ref = A.advect_torch(s64, vel, flags, 0.5, order, 1.0, n)
+    (dr,) = torch.autograd.grad(ref, [s64], torch.tensor(g))
+    bad = np.abs(out.detach().cpu().numpy() - ref.detach().numpy()) > 2e-5
+    assert bad.mean() < 2e-3, bad.mean()
+    if bad.any():     # a clamp decision on the bound differs: compare the gradient away from those outputs only loosely
+        assert rel(ds.cpu().numpy(), dr.numpy()) < 5e-2
+    else:
+        assert rel(ds.cpu().numpy(), dr.numpy()) < 1e-5, rel(ds.cpu().numpy(), dr.numpy())
+
+
+
+def test_gan_advect_through_the_builder():
+    """GAN(x).advect(...) as the reference's graph code calls it (multipassGAN-8x.py:1199), run by the session"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import graph as G
+    from mpgan_amd.GAN import GAN
+    from mpgan_amd.session import Session, VariableStore
+    from oracle import advect as A
+    n, h = 6, 16
+    prev = G.get_default_graph()
+    g = G.reset_default_graph()
+    try:
+        src_p = G.placeholder([None, h, h, 1])
+        vel_p = G.placeholder([None, 4, 4, 3])
+        flags_p = G.placeholder([None, h, h, 1])
+        sl = GAN(src_p).advect(src_p, vel_p, flags_p, 0.5, 1, 1.0, startBz=n)
+        mc = GAN(src_p).advect(src_p, vel_p, flags_p, 0.5, 2, 1.0, startBz=n)
+    finally:
+        G._default_graph[0] = prev
+    rng = np.random.default_rng(8)
+    src = rng.random((n, h, h, 1)).astype(np.float32)
+    vel = (rng.standard_normal((n, 4, 4, 3)) * 0.7).astype(np.float32)
+    flags = np.zeros((n, h, h, 1), np.float32)
+    sess = Session(graph=g, variables=VariableStore("cuda:0"), device="cuda:0")
+    got_sl, got_mc = sess.run([sl, mc], {src_p: src, vel_p: vel, flags_p: flags})
+    assert np.abs(got_sl - A.advect(src, vel, flags, 0.5, 1)).max() < 2e-5
+    bad = np.abs(got_mc - A.advect(src, vel, flags, 0.5, 2, 1.0, n)) > 2e-5
+    assert bad.mean() < 2e-3
