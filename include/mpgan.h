@@ -174,6 +174,10 @@ int mpg_pixel_norm(mpg_stream_t stream, const float* x, size_t npix, int c, floa
  * stat: M floats of scratch. */
 int mpg_minibatch_stddev(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int group_size,
                          float* stat, float* y);
+/* its gradient: dx[n,h,w,c] from dy[n,h,w,c+1] (the pass-through channels plus the statistic's dependence on
+ * every member of the group); dstat: M floats of scratch. */
+int mpg_minibatch_stddev_bwd(mpg_stream_t stream, const float* x, const float* dy, int n, int h, int w, int c,
+                             int group_size, float* dstat, float* dx);
 /* y = act(a + b) elementwise (tf.nn.relu(tf.add(..)), multipassGAN-4x.py:523); b may be NULL */
 int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak, float* y);
 

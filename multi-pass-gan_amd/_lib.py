@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mpg_avg_pool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mpg_pixel_norm": (_I, [_P, _P, _Z, _I, _F, _P]),
     "mpg_minibatch_stddev": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "mpg_minibatch_stddev_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mpg_add_act": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     "mpg_axis_zoom_linear": (_I, [_P, _P, _Z, _I, _Z, _P, _I]),
     "mpg_volume_transpose": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P]),

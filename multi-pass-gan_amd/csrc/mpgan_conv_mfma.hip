@@ -811,6 +811,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
 #endif
             // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
             // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
+#if !MPG_KASM
             auto issue_dma = [&]() {
                 if (g_next < G && st * 8 >= (g_next - 1) * sg.tp) {
                     dma_image(g_next);
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 }
                 dma_stage(st + D);
             };
+#endif
 #if MPG_KASM
             // The LDS-DMA pieces of this stage are spread over its MFMA groups (one piece at a time between the MFMAs)
             // instead of being issued as a burst behind the barrier: a burst of WAVES x (NI + image pieces) 1-KiB

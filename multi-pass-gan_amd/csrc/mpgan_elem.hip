@@ -196,6 +196,50 @@ __global__ void mbstd_concat_kernel(const float* __restrict__ x, const float* __
     y[idx] = ch < c ? x[pix * c + ch] : stat[n % m] * inv_hwc;
 }
 
+// backward.  dstat[m] = sum over the group's members and pixels of dy[.., c] (the broadcast statistic's gradient).
+__global__ __launch_bounds__(256) void mbstd_bwd_stat_kernel(const float* __restrict__ dy, int n, int m, size_t npix_per, int c,
+                                                             float* __restrict__ dstat) {
+    __shared__ float red[BLK];
+    const int mi = blockIdx.y;
+    const int g = n / m;
+    float s = 0.f;
+    const size_t total = (size_t)g * npix_per;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < total; i += (size_t)gridDim.x * BLK) {
+        const size_t k = i / npix_per, p = i - k * npix_per;
+        s += dy[(((size_t)k * m + mi) * npix_per + p) * (c + 1) + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = BLK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(dstat + mi, red[0]);
+}
+
+// dx[k,i] = dy[k,i (channels < c)] + dstat[m] / hwc * (x[k,i] - mean_i) / (g * sqrt(var_i + 1e-8))
+__global__ void mbstd_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ dstat,
+                                 int g, int m, size_t hwc, int c, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const int mi = blockIdx.y;
+    if (i >= hwc) return;
+    float mean = 0.f;
+    for (int k = 0; k < g; ++k) mean += x[((size_t)k * m + mi) * hwc + i];
+    mean /= (float)g;
+    float var = 0.f;
+    for (int k = 0; k < g; ++k) {
+        const float d = x[((size_t)k * m + mi) * hwc + i] - mean;
+        var = fmaf(d, d, var);
+    }
+    const float coef = dstat[mi] / ((float)hwc * (float)g * sqrtf(var / (float)g + 1e-8f));
+    const size_t pix = i / c;
+    const int ch = (int)(i - pix * c);
+    for (int k = 0; k < g; ++k) {
+        const size_t row = (size_t)k * m + mi;
+        dx[row * hwc + i] = dy[(row * (hwc / c) + pix) * (c + 1) + ch] + coef * (x[row * hwc + i] - mean);
+    }
+}
+
 __global__ void add_act_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, int act,
                                float leak, float* __restrict__ y) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
@@ -473,6 +517,25 @@ extern "C" int mpg_minibatch_stddev(mpg_stream_t stream, const float* x, int n, 
     hipLaunchKernelGGL(mbstd_concat_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, stat, m, (size_t)h * w, c, total,
                        1.f / (float)hwc, y);
     MPG_LAUNCH_CHECK("mbstd kernels");
+}
+
+extern "C" int mpg_minibatch_stddev_bwd(mpg_stream_t stream, const float* x, const float* dy, int n, int h, int w, int c,
+                                        int group_size, float* dstat, float* dx) {
+    MPG_REQUIRE(x && dy && dstat && dx, "mpg_minibatch_stddev_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && group_size >= 1, "mpg_minibatch_stddev_bwd: bad shape");
+    const int g = group_size < n ? group_size : n;
+    MPG_REQUIRE(n % g == 0, "mpg_minibatch_stddev_bwd: batch %d is not divisible by the group size %d", n, g);
+    const int m = n / g;
+    const size_t hwc = (size_t)h * w * c;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = mpg::zero_async(dstat, (size_t)m * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_minibatch_stddev_bwd: zero");
+    const size_t per_group = (size_t)g * h * w;
+    unsigned bx = (unsigned)((per_group + BLK * 4 - 1) / (BLK * 4));
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(mbstd_bwd_stat_kernel, dim3(bx, m), dim3(BLK), 0, s, dy, n, m, (size_t)h * w, c, dstat);
+    hipLaunchKernelGGL(mbstd_bwd_kernel, dim3(grid_for(hwc), m), dim3(BLK), 0, s, x, dy, dstat, g, m, hwc, c, dx);
+    MPG_LAUNCH_CHECK("mbstd backward kernels");
 }
 
 extern "C" int mpg_add_act(mpg_stream_t stream, const float* a, const float* b, size_t n, int act, float leak,

@@ -339,6 +339,20 @@ class AvgPoolFn(torch.autograd.Function):
         return train_ops.avg_pool2_bwd(dy, *ctx.hw)
 
 
+class MinibatchStddevFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group_size):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.group_size = group_size
+        return ops.minibatch_stddev(x, group_size)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return train_ops.minibatch_stddev_bwd(dy, x, ctx.group_size), None
+
+
 class PixelNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps):
@@ -554,9 +568,10 @@ class TrainSession(object):
             return train_ops.advect(src, vel.detach(), flags.detach(), at["dt"], at["order"], at["strength"], at["start_bz"])
         if op == "minibatch_stddev":
             x = ev(n.inputs[0])
-            if x.requires_grad:
-                raise NotImplementedError("gradient of minibatch_stddev_layer (use_mb_stddev is 0 in every reference run)")
-            return ops.minibatch_stddev(x.contiguous(), n.attrs["group_size"])
+            if x.requires_grad and self._higher(n):
+                raise NotImplementedError("second-order gradient of minibatch_stddev_layer (use_mb_stddev with the "
+                                          "WGAN-GP penalty; 0 in every reference run)")
+            return MinibatchStddevFn.apply(x, n.attrs["group_size"])
         if op == "resize":
             x = ev(n.inputs[0])
             if n.attrs["method"] == 1:

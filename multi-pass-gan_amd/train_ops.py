@@ -284,6 +284,19 @@ def advect(source, vel, flags, dt, order, strength=0.0, start_bz=15):
     return _MacCormackFn.apply(source, vel_c, flags, float(strength))
 
 
+def minibatch_stddev_bwd(dy, x, group_size):
+    """gradient of GAN.minibatch_stddev_layer (GAN.py:476-488) with respect to its input"""
+    lib = _lib.load()
+    dy, x = _cont(dy, "dy"), _cont(x, "x")
+    n, h, w, c = x.shape
+    g = min(group_size, n)
+    dstat = torch.empty((n // g,), dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    _lib.check(lib.mpg_minibatch_stddev_bwd(_stream(), _ptr(x), _ptr(dy), n, h, w, c, group_size, _ptr(dstat), _ptr(dx)),
+               "mpg_minibatch_stddev_bwd")
+    return dx
+
+
 def pair_reduce(a, b, mode):
     """0-dim tensor: sum |a - b| (mode 0) or sum (a - b)^2 (mode 1)"""
     lib = _lib.load()

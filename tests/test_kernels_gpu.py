@@ -388,6 +388,26 @@ def test_minibatch_stddev(gpu_ops, n, group):
     assert np.allclose(y[..., 5], ref[..., 5], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,group", [(8, 4), (3, 4), (6, 2)])
+def test_minibatch_stddev_gradient(n, group):
+    """backward of the layer against autograd on a float64 torch statement of GAN.py:476-488"""
+    from mpgan_amd.train import MinibatchStddevFn
+    x = _rng(5 + n).standard_normal((n, 4, 6, 3)).astype(np.float32)
+    dy = _rng(6 + n).standard_normal((n, 4, 6, 4)).astype(np.float32)
+    xt = _t(x).requires_grad_(True)
+    y = MinibatchStddevFn.apply(xt, group)
+    (dx,) = torch.autograd.grad(y, [xt], _t(dy))
+    x64 = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    g = min(group, n)
+    v = x64.reshape(g, -1, 4, 6, 3)
+    v = v - v.mean(dim=0, keepdim=True)
+    v = torch.sqrt((v * v).mean(dim=0) + 1e-8).mean(dim=(1, 2, 3), keepdim=True)
+    ref = torch.cat([x64, v.repeat(g, 4, 6, 1)], dim=3)
+    assert rel_l2(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-6
+    (dr,) = torch.autograd.grad(ref, [x64], torch.tensor(dy, dtype=torch.float64))
+    assert rel_l2(dx.cpu().numpy(), dr.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("axis", [0, 1, 2])
 @pytest.mark.parametrize("factor", [4, 8])
 def test_axis_zoom_matches_scipy(gpu_ops, axis, factor):
