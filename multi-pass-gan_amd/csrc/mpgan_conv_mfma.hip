@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const
 
         // ---- image DMA: piece pc = 4*i + wave covers 64 pixels of one plane of one group ----
         const size_t plane_px = (size_t)sg.hs * sg.ws;
-        [[maybe_unused]] auto dma_image = [&](int chunk) {
+        auto dma_image = [&](int chunk) {
             char* buf = img_lds + (chunk & 1) * a.img_bytes;
             for (int i = 0; i < sg.ni_img; ++i) {
                 const int pc = 4 * i + wave_u;                 // piece of this wave
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
         for (int pt = 0; pt < PT; ++pt) pixb[pt] = ((PT * wave + pt) * sg.iw + r) * 16;
 
         const size_t plane_px = (size_t)sg.hs * sg.ws;
-        auto dma_image = [&](int chunk) {
+        [[maybe_unused]] auto dma_image = [&](int chunk) {
             char* buf = img_lds + (chunk & 1) * a.img_bytes;
             for (int i = 0; i < sg.ni_img; ++i) {
                 const int pc = WAVES * i + wave_u;
