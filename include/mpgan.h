@@ -165,6 +165,13 @@ int mpg_resize_bilinear(mpg_stream_t stream, const float* x, int n, int h, int w
  * (avg_depool(mode=2), multipassGAN-out.py:330) */
 int mpg_resize_bicubic(mpg_stream_t stream, const float* x, int n, int h, int w, int c,
                        float* y, int oh, int ow);
+/* tf.nn.max_pool VALID, k x k window, stride s (GAN.max_pool, GAN.py:152-159).  arg (may be NULL; one byte per output)
+ * receives the window position dy * k + dx of the first maximum in scan order; mpg_max_pool_bwd sends dy there
+ * (dx [n,h,w,c] is overwritten). */
+int mpg_max_pool(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int k, int s, float* y,
+                 unsigned char* arg);
+int mpg_max_pool_bwd(mpg_stream_t stream, const float* dy, const unsigned char* arg, int n, int h, int w, int c,
+                     int k, int s, float* dx);
 /* tf.nn.avg_pool 2x2 VALID (GAN.py:162-169) */
 int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y);
 /* GAN.pixel_norm standalone (GAN.py:472-474) */

@@ -100,9 +100,11 @@ class GAN(object):
             self.layer = activation_function(self.layer)
         return self.layer, layer_lin
 
-    # GAN.py:152-159 (not used by any model function of the hot path)
+    # GAN.py:152-159
     def max_pool(self, window_size=[2], window_stride=[2]):
-        raise NotImplementedError("max_pool is not on the multi-pass hot path (GAN.py:152-159)")
+        self.layer = G.max_pool(self.layer, window_size[0], window_stride[0])
+        _say("Max Pool {}: {}".format(window_size, self.layer.get_shape()))
+        return self.layer
 
     # GAN.py:162-169
     def avg_pool(self, window_size=[2], window_stride=[2]):

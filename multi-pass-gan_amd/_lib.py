@@ -95,6 +95,8 @@ PROTOTYPES = {
     "mpg_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
     "mpg_resize_bicubic": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
     "mpg_avg_pool2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "mpg_max_pool": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mpg_max_pool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mpg_pixel_norm": (_I, [_P, _P, _Z, _I, _F, _P]),
     "mpg_minibatch_stddev": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mpg_minibatch_stddev_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

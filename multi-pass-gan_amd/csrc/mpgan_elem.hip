@@ -139,6 +139,49 @@ __global__ void avg_pool2_kernel(const float* __restrict__ x, int n, int h, int 
     y[idx] = (base[0] + base[c] + base[(size_t)w * c] + base[(size_t)w * c + c]) * 0.25f;
 }
 
+// tf.nn.max_pool VALID, window k x k, stride s.  arg (optional) receives the window position (dy * k + dx) of the
+// FIRST maximum in scan order: where TensorFlow's MaxPoolGrad sends the gradient.
+__global__ void max_pool_kernel(const float* __restrict__ x, int n, int h, int w, int c, int k, int s,
+                                float* __restrict__ y, unsigned char* __restrict__ arg) {
+    const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const float* base = x + (((size_t)b * h + (size_t)s * oy) * w + (size_t)s * ox) * c + ch;
+    float best = base[0];
+    int at = 0;
+    for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) {
+            const float v = base[((size_t)dy * w + dx) * c];
+            if (v > best) { best = v; at = dy * k + dx; }
+        }
+    y[idx] = best;
+    if (arg != nullptr) arg[idx] = (unsigned char)at;
+}
+
+// gradient: every output sends dy to its arg position (windows overlap when s < k: atomics; dx is zeroed first)
+__global__ void max_pool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ arg, int n, int h, int w,
+                                    int c, int k, int s, float* __restrict__ dx) {
+    const int oh = (h - k) / s + 1, ow = (w - k) / s + 1;
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    const size_t total = (size_t)n * oh * ow * c;
+    if (idx >= total) return;
+    const int ch = idx % c;
+    size_t p = idx / c;
+    const int ox = p % ow; p /= ow;
+    const int oy = p % oh;
+    const int b = p / oh;
+    const int at = arg[idx];
+    float* dst = dx + (((size_t)b * h + (size_t)s * oy + at / k) * w + (size_t)s * ox + at % k) * c + ch;
+    if (s >= k) *dst = dy[idx];
+    else atomicAdd(dst, dy[idx]);
+}
+
 // `lanes` (a power of two <= 64) consecutive lanes share one pixel and stride its channels, so a wave reads
 // contiguous memory; the sum of squares is folded with shuffles inside the lane group
 __global__ void pixel_norm_kernel(const float* __restrict__ x, size_t npix, int c, int lanes, float eps,
@@ -480,6 +523,27 @@ extern "C" int mpg_conv2d_direct(mpg_stream_t stream, const float* x, int n, int
 MPG_RESIZE_ENTRY(mpg_resize_nearest, resize_nearest_kernel)
 MPG_RESIZE_ENTRY(mpg_resize_bilinear, resize_bilinear_kernel)
 MPG_RESIZE_ENTRY(mpg_resize_bicubic, resize_bicubic_kernel)
+
+extern "C" int mpg_max_pool(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int k, int s, float* y,
+                            unsigned char* arg) {
+    MPG_REQUIRE(x && y, "mpg_max_pool: null pointer");
+    MPG_REQUIRE(n >= 1 && c >= 1 && k >= 1 && k <= 15 && s >= 1 && h >= k && w >= k, "mpg_max_pool: bad shape");
+    const size_t total = (size_t)n * ((h - k) / s + 1) * ((w - k) / s + 1) * c;
+    hipLaunchKernelGGL(max_pool_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, x, n, h, w, c, k, s, y, arg);
+    MPG_LAUNCH_CHECK("max_pool_kernel");
+}
+
+extern "C" int mpg_max_pool_bwd(mpg_stream_t stream, const float* dy, const unsigned char* arg, int n, int h, int w, int c,
+                                int k, int s, float* dx) {
+    MPG_REQUIRE(dy && arg && dx, "mpg_max_pool_bwd: null pointer");
+    MPG_REQUIRE(n >= 1 && c >= 1 && k >= 1 && k <= 15 && s >= 1 && h >= k && w >= k, "mpg_max_pool_bwd: bad shape");
+    hipError_t e = mpg::zero_async(dx, (size_t)n * h * w * c * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_max_pool_bwd: zero");
+    const size_t total = (size_t)n * ((h - k) / s + 1) * ((w - k) / s + 1) * c;
+    hipLaunchKernelGGL(max_pool_bwd_kernel, dim3(grid_for(total)), dim3(BLK), 0, (hipStream_t)stream, dy, arg, n, h, w, c, k,
+                       s, dx);
+    MPG_LAUNCH_CHECK("max_pool_bwd_kernel");
+}
 
 extern "C" int mpg_avg_pool2(mpg_stream_t stream, const float* x, int n, int h, int w, int c, float* y) {
     MPG_REQUIRE(x && y, "mpg_avg_pool2: null pointer");

@@ -260,6 +260,14 @@ def resize_images(x, size, method=0):
     return Node("resize", [x], shape=(x.shape[0], oh, ow, x.shape[3]), oh=oh, ow=ow, method=int(method))
 
 
+def max_pool(x, k=2, s=2):
+    """tf.nn.max_pool(x, [1,k,k,1], [1,s,s,1], VALID) (GAN.py:152-159)"""
+    if x.shape[1] < k or x.shape[2] < k:
+        raise GraphError("max_pool: window %d does not fit %s" % (k, x.shape))
+    return Node("max_pool", [x], shape=(x.shape[0], (x.shape[1] - k) // s + 1, (x.shape[2] - k) // s + 1, x.shape[3]),
+                k=int(k), s=int(s))
+
+
 def avg_pool(x, k=2, s=2):
     if k != 2 or s != 2:
         raise GraphError("avg_pool: only 2x2 stride 2 is implemented")

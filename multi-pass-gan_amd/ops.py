@@ -366,6 +366,20 @@ def resize_images(x, oh, ow, method):
     raise _lib.MpgError("resize method %r not supported" % (method,))
 
 
+def max_pool(x, k=2, s=2, want_arg=False):
+    """tf.nn.max_pool(x, k, s, VALID) (GAN.py:152-159); with want_arg also the uint8 window positions of the maxima"""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    n, h, w, c = x.shape
+    if h < k or w < k:
+        raise _lib.MpgError("max_pool: window %d does not fit %dx%d" % (k, h, w))
+    oh, ow = (h - k) // s + 1, (w - k) // s + 1
+    y = torch.empty((n, oh, ow, c), dtype=torch.float32, device=x.device)
+    arg = torch.empty((n, oh, ow, c), dtype=torch.uint8, device=x.device) if want_arg else None
+    _lib.check(lib.mpg_max_pool(_stream(), _ptr(x), n, h, w, c, k, s, _ptr(y), _ptr(arg) if want_arg else None), "mpg_max_pool")
+    return (y, arg) if want_arg else y
+
+
 def avg_pool2(x):
     lib = _lib.load()
     x = _dev(x, "x")

@@ -538,6 +538,9 @@ class Session(object):
         if op == "avg_pool":
             x = n.inputs[0]
             return [x], lambda env: ops.avg_pool2(self._f32(env, x))
+        if op == "max_pool":
+            x = n.inputs[0]
+            return [x], lambda env: ops.max_pool(self._f32(env, x), n.attrs["k"], n.attrs["s"])
         if op == "minibatch_stddev":
             x = n.inputs[0]
             return [x], lambda env: ops.minibatch_stddev(self._f32(env, x), n.attrs["group_size"])

@@ -339,6 +339,21 @@ class AvgPoolFn(torch.autograd.Function):
         return train_ops.avg_pool2_bwd(dy, *ctx.hw)
 
 
+class MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, k, s):
+        x = x.contiguous()
+        y, arg = ops.max_pool(x, k, s, want_arg=True)
+        ctx.save_for_backward(arg)
+        ctx.geom = (x.shape[1], x.shape[2], k, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        return train_ops.max_pool_bwd(dy, arg, *ctx.geom), None, None
+
+
 class MinibatchStddevFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group_size):
@@ -561,6 +576,10 @@ class TrainSession(object):
             x = None if n.attrs["zero_x"] else ev(n.inputs[0])
             y = ev(n.inputs[-1])
             return (Lerp2Fn if self._higher(n) else LerpFn).apply(x, y, t)
+        if op == "max_pool":
+            if self._higher(n):
+                raise NotImplementedError("second-order gradient through max_pool (no reference network uses it)")
+            return MaxPoolFn.apply(ev(n.inputs[0]), n.attrs["k"], n.attrs["s"])
         if op == "advect":
             src, vel = ev(n.inputs[0]), ev(n.inputs[1])
             flags = ev(n.inputs[2]) if len(n.inputs) > 2 else torch.zeros_like(src[..., :1])

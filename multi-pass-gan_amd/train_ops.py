@@ -142,6 +142,15 @@ def resize_nearest_bwd(dy, h, w):
     return dx
 
 
+def max_pool_bwd(dy, arg, h, w, k, s):
+    lib = _lib.load()
+    dy = _cont(dy, "dy")
+    n, _, _, c = dy.shape
+    dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mpg_max_pool_bwd(_stream(), _ptr(dy), _ptr(arg), n, h, w, c, k, s, _ptr(dx)), "mpg_max_pool_bwd")
+    return dx
+
+
 def avg_pool2_bwd(dy, h, w):
     lib = _lib.load()
     dy = _cont(dy, "dy")

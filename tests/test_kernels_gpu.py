@@ -388,6 +388,31 @@ def test_minibatch_stddev(gpu_ops, n, group):
     assert np.allclose(y[..., 5], ref[..., 5], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,s", [(2, 2), (3, 2), (3, 1)])
+def test_max_pool_forward_and_gradient(gpu_ops, k, s):
+    """GAN.max_pool (GAN.py:152-159): tf.nn.max_pool VALID and its gradient (to the first maximum of a window)"""
+    from mpgan_amd.train import MaxPoolFn
+    x = _rng(70 + k).standard_normal((2, 9, 11, 5)).astype(np.float32)
+    x[0, :4, :4, 0] = 1.5                                              # ties
+    y = gpu_ops.max_pool(_t(x), k, s).cpu().numpy()
+    assert np.array_equal(y, O.max_pool(x, k, s))
+    xt = _t(x).requires_grad_(True)
+    out = MaxPoolFn.apply(xt, k, s)
+    dy = _rng(71).standard_normal(tuple(out.shape)).astype(np.float32)
+    (dx,) = torch.autograd.grad(out, [xt], _t(dy))
+    # reference: scan every window in (dy, dx) order, first strict maximum wins
+    want = np.zeros(x.shape, np.float64)
+    n, h, w, c = x.shape
+    for b in range(n):
+        for oy in range(y.shape[1]):
+            for ox in range(y.shape[2]):
+                win = x[b, oy * s:oy * s + k, ox * s:ox * s + k, :].reshape(k * k, c)
+                at = win.argmax(axis=0)                                # numpy returns the first maximum
+                for ch in range(c):
+                    want[b, oy * s + at[ch] // k, ox * s + at[ch] % k, ch] += dy[b, oy, ox, ch]
+    assert np.abs(dx.cpu().numpy() - want).max() < 1e-5
+
+
 @pytest.mark.parametrize("n,group", [(8, 4), (3, 4), (6, 2)])
 def test_minibatch_stddev_gradient(n, group):
     """backward of the layer against autograd on a float64 torch statement of GAN.py:476-488"""
