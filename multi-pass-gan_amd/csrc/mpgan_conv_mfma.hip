@@ -1162,34 +1162,43 @@ __device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, in
     }
 }
 
-// block = 32 x 8 output pixels.  Per segment the halo tile is converted to fp32 ONCE into LDS ([pixel][8
-// channels], zero outside the image), then every thread walks its taps with two ds_read_b128 and
-// cin x COUT FMAs whose weights are wave-uniform scalar loads.
-constexpr int SM_TW = 32, SM_TH = 8;
+// block = 64 x 16 output pixels; a thread owns a COLUMN of four of them (rows 4 yg .. 4 yg + 3 at column lx), so that
+// consecutive lanes read consecutive 16-byte LDS words (no bank conflicts) and the rows a thread reads for one filter
+// column serve all of its pixels: (4 + kh - 1) pixel reads per kx instead of 4 kh, and every tap's weight block --
+// LDS broadcasts of the dense [tap][CINB][COUT] table -- feeds four pixels.  Per segment the halo tile is converted to
+// fp32 ONCE into LDS as planes of four channels ([plane][row][col] float4, zero outside the image).
+#ifndef MPG_SM_RPT
+#define MPG_SM_RPT 4
+#endif
+constexpr int SM_TW = 64, SM_RPT = MPG_SM_RPT, SM_TH = 4 * SM_RPT, SM_KMAX = 7;
 
 // COUT / CINB: output channels / input channels per segment rounded up to 1, 2, 4, 8 (compile-time loop bounds: the
 // weight table holds zeros beyond cin and cout, a G8 group holds zeros beyond its channels)
 template <int COUT, int CINB>
 __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
-    // LDS sized by the launch for the largest segment (5x5: 20 KB, so eight blocks = 32 waves share a CU and the
-    // 2048 tiles of 8 slices of 256^2 are one round): halo tile, then the segment's weight table (LDS broadcasts)
     extern __shared__ __attribute__((aligned(16))) float small_lds[];
-    float* tile = small_lds;
+    constexpr int PL = (CINB + 3) / 4;                 // planes of four channels
+    constexpr int CP = CINB < 4 ? CINB : 4;            // channels used of a plane
+    float4* tile = reinterpret_cast<float4*>(small_lds);
     float* wl = small_lds + a.tile_floats;
     const int tid = threadIdx.x;
-    const int tx = tid % SM_TW, ty = tid / SM_TW;
+    const int lx = tid % SM_TW, yg = tid / SM_TW;
     const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
-    const int x = x0 + tx, y = y0 + ty;
-    float acc[8];          // COUT live accumulators (cout rounded up to 1, 2, 4, 8); the rest stays zero
+    float acc[SM_RPT][COUT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < SM_RPT; ++j)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[j][co] = 0.f;
     for (int s = 0; s < a.nseg; ++s) {
         const SmallSeg& g = a.seg[s];
         const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
         const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
         const int tw = SM_TW + g.kw - 1, th = SM_TH + g.kh - 1;
         if (s > 0) __syncthreads();
-        for (int p = tid; p < g.kh * g.kw * 64; p += 256) wl[p] = g.w[p];
+        for (int p = tid; p < g.kh * g.kw * CINB * COUT; p += 256) {
+            const int co = p % COUT, ci = (p / COUT) % CINB, tap = p / (COUT * CINB);
+            wl[p] = g.w[tap * 64 + ci * 8 + co];
+        }
         for (int p = tid; p < tw * th; p += 256) {
             const int hy = p / tw, hx = p - hy * tw;
             const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
@@ -1198,77 +1207,98 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
                 g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
             }
-            float4* dst = reinterpret_cast<float4*>(tile + p * 8);
-            dst[0] = make_float4(v[0], v[1], v[2], v[3]);
-            dst[1] = make_float4(v[4], v[5], v[6], v[7]);
+            tile[p] = make_float4(v[0], v[1], v[2], v[3]);
+            if (PL > 1) tile[th * tw + p] = make_float4(v[4], v[5], v[6], v[7]);
         }
         __syncthreads();
-        for (int ky = 0; ky < g.kh; ++ky) {
-            for (int kx = 0; kx < g.kw; ++kx) {
-                const float4* src = reinterpret_cast<const float4*>(tile + ((ty + ky) * tw + tx + kx) * 8);
-                const float4 lo4 = src[0];
-                const float* wt = wl + (ky * g.kw + kx) * 64;
-                float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, 0.f, 0.f, 0.f, 0.f};
-                if (CINB > 4) {
-                    const float4 hi4 = src[1];
-                    v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-                }
+        const int kh = g.kh;
+        for (int kx = 0; kx < g.kw; ++kx) {
+            // the rows this thread's four pixels see through filter column kx
+            float rows[SM_RPT + SM_KMAX - 1][CINB];
 #pragma unroll
-                for (int ci = 0; ci < CINB; ++ci) {
-                    {
-                        float wv[8];
-                        if (COUT > 4) {
-                            const float4 w0 = *reinterpret_cast<const float4*>(wt + ci * 8);
-                            const float4 w1 = *reinterpret_cast<const float4*>(wt + ci * 8 + 4);
-                            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w;
-                            wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
-                        } else if (COUT > 2) {
-                            const float4 w0 = *reinterpret_cast<const float4*>(wt + ci * 8);
-                            wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w;
+            for (int r = 0; r < SM_RPT + SM_KMAX - 1; ++r) {
+                if (r < SM_RPT + kh - 1) {
+                    const float4* src = tile + (yg * SM_RPT + r) * tw + lx + kx;
+                    const float4 p0 = src[0];
+                    rows[r][0] = p0.x;
+                    if (CP > 1) rows[r][1] = p0.y;
+                    if (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
+                    if (PL > 1) {
+                        const float4 p1 = src[th * tw];
+                        rows[r][4] = p1.x; rows[r][5] = p1.y; rows[r][6] = p1.z; rows[r][7] = p1.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int ky = 0; ky < SM_KMAX; ++ky) {
+                if (ky < kh) {
+                    const float* wt = wl + (ky * g.kw + kx) * (CINB * COUT);
+#pragma unroll
+                    for (int ci = 0; ci < CINB; ++ci) {
+                        float wv[COUT];
+                        if (COUT >= 4) {
+#pragma unroll
+                            for (int q = 0; q < COUT / 4; ++q) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(wt + ci * COUT + 4 * q);
+                                wv[4 * q] = w4.x; wv[4 * q + 1] = w4.y; wv[4 * q + 2] = w4.z; wv[4 * q + 3] = w4.w;
+                            }
+                        } else if (COUT == 2) {
+                            const float2 w2 = *reinterpret_cast<const float2*>(wt + ci * 2);
+                            wv[0] = w2.x; wv[1] = w2.y;
                         } else {
-                            const float2 w0 = *reinterpret_cast<const float2*>(wt + ci * 8);
-                            wv[0] = w0.x; wv[1] = w0.y;
+                            wv[0] = wt[ci];
                         }
 #pragma unroll
-                        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wv[co], acc[co]);
+                        for (int j = 0; j < SM_RPT; ++j)
+#pragma unroll
+                            for (int co = 0; co < COUT; ++co) acc[j][co] = fmaf(rows[j + ky][ci], wv[co], acc[j][co]);
                     }
                 }
             }
         }
     }
-    if (x >= a.w || y >= a.h) return;
+    const int x = x0 + lx;
+    if (x >= a.w) return;
     const float unscale = a.in_amax != nullptr ? 1.f / mpg::pow2_scale(*a.in_amax) : 1.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-        acc[j] = j < a.cout ? mpg::apply_act(acc[j] * unscale + (a.bias != nullptr ? a.bias[j] : 0.f), a.act, a.leak) : 0.f;
     const size_t plane_px = (size_t)a.h * a.w;
-    const size_t pix = (size_t)y * a.w + x;
-    if (a.y != nullptr) {
-        float* dst = a.y + ((size_t)b * plane_px + pix) * a.cout;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < a.cout) dst[j] = acc[j];
-    }
-    if (a.y_g8 != nullptr) {
-        half8 hi, lo;
+    for (int j = 0; j < SM_RPT; ++j) {
+        const int y = y0 + yg * SM_RPT + j;
+        if (y >= a.h) break;
+        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            hi[j] = (_Float16)acc[j];
-            lo[j] = (_Float16)(acc[j] - (float)hi[j]);
+        for (int q = 0; q < 8; ++q)
+            o[q] = (q < COUT && q < a.cout) ? mpg::apply_act(acc[j][q < COUT ? q : 0] * unscale + (a.bias != nullptr ? a.bias[q] : 0.f),
+                                                              a.act, a.leak)
+                                            : 0.f;
+        const size_t pix = (size_t)y * a.w + x;
+        if (a.y != nullptr) {
+            float* dst = a.y + ((size_t)b * plane_px + pix) * a.cout;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < a.cout) dst[q] = o[q];
         }
-        char* dst = a.y_g8 + ((size_t)b * 2 * plane_px + pix) * 16;
-        *reinterpret_cast<half8*>(dst) = hi;
-        *reinterpret_cast<half8*>(dst + plane_px * 16) = lo;
-    }
-    if (a.y_g8c != nullptr) {
-        half8 hi;
+        if (a.y_g8 != nullptr) {
+            half8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hi[j] = (_Float16)acc[j];
-        char* dst = a.y_g8c + ((size_t)b * 2 * plane_px + pix) * 16;
-        *reinterpret_cast<half8*>(dst) = hi;
-        *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(acc);
+            for (int q = 0; q < 8; ++q) {
+                hi[q] = (_Float16)o[q];
+                lo[q] = (_Float16)(o[q] - (float)hi[q]);
+            }
+            char* dst = a.y_g8 + ((size_t)b * 2 * plane_px + pix) * 16;
+            *reinterpret_cast<half8*>(dst) = hi;
+            *reinterpret_cast<half8*>(dst + plane_px * 16) = lo;
+        }
+        if (a.y_g8c != nullptr) {
+            half8 hi;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) hi[q] = (_Float16)o[q];
+            char* dst = a.y_g8c + ((size_t)b * 2 * plane_px + pix) * 16;
+            *reinterpret_cast<half8*>(dst) = hi;
+            *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(o);
+        }
     }
 }
 
@@ -1605,10 +1635,10 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
                 const int px = (SM_TH + g.kh - 1) * (SM_TW + g.kw - 1);
                 tile_px = px > tile_px ? px : tile_px;
             }
-            sa.tile_floats = tile_px * 8;
-            const size_t small_lds = ((size_t)tile_px * 8 + (size_t)tmax * 64) * sizeof(float);
             const int cob = d->cout == 1 ? 1 : d->cout == 2 ? 2 : d->cout <= 4 ? 4 : 8;
             const int cib = cmax == 1 ? 1 : cmax == 2 ? 2 : cmax <= 4 ? 4 : 8;
+            sa.tile_floats = tile_px * 4 * ((cib + 3) / 4);       // one or two planes of four channels
+            const size_t small_lds = ((size_t)sa.tile_floats + (size_t)tmax * cib * cob) * sizeof(float);
             switch (cob * 16 + cib) {
 #define MPG_SMALL(CO, CI) \
     case CO * 16 + CI: hipLaunchKernelGGL((conv_small_kernel<CO, CI>), sg, dim3(256), small_lds, (hipStream_t)stream, sa); break;
