@@ -52,6 +52,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the oracle parity it carries)")
     ap.add_argument("--no-second-prec", action="store_true", help="skip the second timed figure (value_f16x3)")
     ap.add_argument("--cpu-slices", type=int, default=12, help="slices per pass of the CPU leg (>= 8)")
+    ap.add_argument("--sharded-error", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="HIP streams the independent volumes are dealt to (multipass.two_pass_4x_batch lanes)")
     ap.add_argument("--mode", default="both", choices=("both", "sharded", "replicas"),
                     help="N > 1: `sharded` = slices of every volume over the ranks + all-gather between the passes "
                          "(north_star; this is `value`), `replicas` = whole volumes per rank, no exchange; both = time both")
@@ -72,6 +75,15 @@ def launch_self(args, argv):
     from mpgan_amd import launch
     rc, out = launch.spawn_ranks(os.path.abspath(__file__), argv, args.gpus, timeout=args.launch_timeout)
     line = launch.last_json_line(out)
+    if (rc != 0 or line is None) and args.mode != "replicas":
+        # the sharded path needs RCCL (all-gather between the passes); if that job dies, still measure the partition
+        # that needs no exchange -- whole volumes per rank, control traffic over gloo -- and say so in the line
+        sys.stderr.write(out)
+        sys.stderr.write("bench.py: the sharded run failed (rc %s); measuring whole volumes per rank instead\n" % rc)
+        rc, out = launch.spawn_ranks(os.path.abspath(__file__), list(argv) + ["--mode", "replicas", "--sharded-error",
+                                                                             "rc %s" % rc],
+                                     args.gpus, timeout=args.launch_timeout)
+        line = launch.last_json_line(out)
     if line is not None:
         print(line)
     else:
@@ -248,12 +260,14 @@ def main(argv=None):
 
     def timed(ga, gb, replicas):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks"""
+        lanes = [(ga.clone(), gb.clone()) for _ in range(max(args.lanes, 1) - 1)]
+
         def step():
             # the volumes are independent: their passes are pipelined by one volume so that the all-gather of
             # one volume's slabs overlaps the convolutions of its neighbours (N > 1); same arithmetic either way
             if replicas:
-                return MP.two_pass_4x_batch(ga, gb, mine, UP, batch=args.slice_batch, comm=None)
-            return MP.two_pass_4x_batch(ga, gb, lows, UP, batch=args.slice_batch, comm=comm)
+                return MP.two_pass_4x_batch(ga, gb, mine, UP, batch=args.slice_batch, comm=None, lanes=lanes)
+            return MP.two_pass_4x_batch(ga, gb, lows, UP, batch=args.slice_batch, comm=comm, lanes=lanes)
         for _ in range(args.warmup):
             step()
         if comm is not None:
@@ -293,13 +307,15 @@ def main(argv=None):
     if rank != 0:
         return 0
     vol_per_s = n_vol * args.steps / dt
+    if args.sharded_error:
+        extra["sharded_error"] = args.sharded_error
     replicas_only = world > 1 and args.mode == "replicas"
     result = {
         "metric": "volumes/sec (4x two-pass generator inference, 64^3->256^3 density-only)",
         "value": round(vol_per_s, 4),
         "unit": "volumes/s",
         "n_gpus": world,
-        "rccl_ranks": world,
+        "rccl_ranks": 0 if (world > 1 and args.mode == "replicas") else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -314,6 +330,7 @@ def main(argv=None):
             "volumes_per_step": n_vol,
             "slices_per_volume": SLICES_PER_VOLUME,
             "slice_batch": args.slice_batch,
+            "lanes": max(args.lanes, 1),
             "parallelism": ("whole volumes per rank x%d, no exchange" % world if replicas_only else
                             "slice-axis sharding x%d + all-gather between passes, exchanges overlapped with the next volume" % world)
                            if world > 1 else "single GPU",

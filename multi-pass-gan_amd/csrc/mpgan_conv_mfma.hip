@@ -1171,6 +1171,15 @@ __device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, in
 #define MPG_SM_RPT 4
 #endif
 constexpr int SM_TW = 64, SM_RPT = MPG_SM_RPT, SM_TH = 4 * SM_RPT, SM_KMAX = 7;
+#ifndef MPG_DIAG_SMALL
+#define MPG_DIAG_SMALL 0
+#endif
+#ifndef MPG_SMALL_INV
+#define MPG_SMALL_INV 0
+#endif
+#if MPG_DIAG_SMALL
+__device__ unsigned g_small_diag[2];
+#endif
 
 // COUT / CINB: output channels / input channels per segment rounded up to 1, 2, 4, 8 (compile-time loop bounds: the
 // weight table holds zeros beyond cin and cout, a G8 group holds zeros beyond its channels)
@@ -1184,6 +1193,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
     const int tid = threadIdx.x;
     const int lx = tid % SM_TW, yg = tid / SM_TW;
     const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
+#if MPG_SMALL_INV
+    asm volatile("buffer_inv sc0 sc1" ::: "memory");
+#endif
     float acc[SM_RPT][COUT];
 #pragma unroll
     for (int j = 0; j < SM_RPT; ++j)
@@ -1259,6 +1271,38 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             }
         }
     }
+#if MPG_DIAG_SMALL
+    {   // diagnostic: is this block's LDS still what it wrote?  (foreign writes into the allocation)
+        __syncthreads();
+        const SmallSeg& g = a.seg[a.nseg - 1];
+        const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
+        const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
+        const int tw = SM_TW + g.kw - 1, th = SM_TH + g.kh - 1;
+        unsigned bad_w = 0, bad_t = 0;
+        for (int p = tid; p < g.kh * g.kw * CINB * COUT; p += 256) {
+            const int co = p % COUT, ci = (p / COUT) % CINB, tap = p / (COUT * CINB);
+            if (wl[p] != g.w[tap * 64 + ci * 8 + co]) ++bad_w;
+        }
+        for (int p = tid; p < tw * th; p += 256) {
+            const int hy = p / tw, hx = p - hy * tw;
+            const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
+            float v[8];
+            if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
+                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
+            } else {
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
+            const float4 t0 = tile[p];
+            if (t0.x != v[0] || t0.y != v[1] || t0.z != v[2] || t0.w != v[3]) ++bad_t;
+            if (PL > 1) {
+                const float4 t1 = tile[th * tw + p];
+                if (t1.x != v[4] || t1.y != v[5] || t1.z != v[6] || t1.w != v[7]) ++bad_t;
+            }
+        }
+        if (bad_w) atomicAdd(&g_small_diag[0], bad_w);
+        if (bad_t) atomicAdd(&g_small_diag[1], bad_t);
+    }
+#endif
     const int x = x0 + lx;
     if (x >= a.w) return;
     const float unscale = a.in_amax != nullptr ? 1.f / mpg::pow2_scale(*a.in_amax) : 1.f;
@@ -1589,6 +1633,12 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
     MPG_LAUNCH_CHECK("pack_weights_kernel");
 }
 
+#if MPG_DIAG_SMALL
+extern "C" int mpg_debug_small_diag(unsigned* out2) {
+    return hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_small_diag), 8) == hipSuccess ? 0 : 1;
+}
+#endif
+
 extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(d != nullptr, "mpg_conv2d_fused: null desc");
     MPG_REQUIRE(d->n >= 1 && d->h >= 1 && d->w >= 1, "mpg_conv2d_fused: bad shape %d x %d x %d", d->n, d->h, d->w);
@@ -1638,7 +1688,10 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
             const int cob = d->cout == 1 ? 1 : d->cout == 2 ? 2 : d->cout <= 4 ? 4 : 8;
             const int cib = cmax == 1 ? 1 : cmax == 2 ? 2 : cmax <= 4 ? 4 : 8;
             sa.tile_floats = tile_px * 4 * ((cib + 3) / 4);       // one or two planes of four channels
-            const size_t small_lds = ((size_t)sa.tile_floats + (size_t)tmax * cib * cob) * sizeof(float);
+#ifndef MPG_SM_PAD
+#define MPG_SM_PAD 0
+#endif
+            const size_t small_lds = ((size_t)sa.tile_floats + (size_t)tmax * cib * cob) * sizeof(float) + MPG_SM_PAD;
             switch (cob * 16 + cib) {
 #define MPG_SMALL(CO, CI) \
     case CO * 16 + CI: hipLaunchKernelGGL((conv_small_kernel<CO, CI>), sg, dim3(256), small_lds, (hipStream_t)stream, sa); break;

@@ -29,10 +29,22 @@ class _Gathered(object):
 
 
 class Comm(object):
-    def __init__(self, group=None):
+    """`group`: the process group of the data exchanges (RCCL for device tensors).  `host_group`: a gloo group for the
+    control traffic of a measurement (barrier, max over ranks of a host float): it does not depend on RCCL, so a
+    run without a data-path collective (whole volumes per rank) needs no RCCL at all."""
+
+    def __init__(self, group=None, host_group=None):
         self.group = group
+        self.host_group = host_group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+
+    def _data_group(self, t):
+        if t.is_cuda and self.group is None and dist.get_backend() == "gloo":
+            # default group is the gloo control group: the RCCL group is made at the first device exchange
+            # (every rank reaches it at the same point: new_group is collective)
+            self.group = dist.new_group(backend="nccl")
+        return self.group
 
     def all_gather_slabs(self, local, total):
         """local: this rank's contiguous slab [total/world, ...] -> full [total, ...] on every rank"""
@@ -44,7 +56,7 @@ class Comm(object):
         local = local.contiguous()
         full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         if local.is_cuda:
-            dist.all_gather_into_tensor(full, local, group=self.group)
+            dist.all_gather_into_tensor(full, local, group=self._data_group(local))
         else:
             dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group)
         return full
@@ -61,7 +73,7 @@ class Comm(object):
         full = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         if local.is_cuda:
             # RCCL: one flat receive buffer (the slabs are contiguous along the slice axis), no staging copies
-            work = dist.all_gather_into_tensor(full, local, group=self.group, async_op=True)
+            work = dist.all_gather_into_tensor(full, local, group=self._data_group(local), async_op=True)
         else:
             work = dist.all_gather([full[i * per:(i + 1) * per] for i in range(self.world)], local, group=self.group,
                                    async_op=True)
@@ -71,24 +83,37 @@ class Comm(object):
         """data-parallel training: average one flat gradient buffer (one bucket per optimiser) in place"""
         if self.world == 1:
             return flat
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._data_group(flat))
         flat.mul_(1.0 / self.world)
         return flat
 
     def barrier(self):
-        dist.barrier(group=self.group)
+        if self.host_group is not None or dist.get_backend() == "gloo":
+            dist.barrier(group=self.host_group)
+        else:
+            dist.barrier(group=self.group)
 
     def max_float(self, v, device):
-        t = torch.tensor([float(v)], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        if self.host_group is not None or dist.get_backend() == "gloo":
+            t = torch.tensor([float(v)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.host_group)
+        else:
+            t = torch.tensor([float(v)], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
 
-def init_from_env(backend=None):
-    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run; returns (comm, device)."""
+def init_from_env(backend=None, timeout_s=600):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as set by torch.distributed.run; returns (comm, device).
+    On GPUs the default process group is gloo (control traffic: barriers, the max over ranks of a time) and the RCCL
+    group for the device exchanges is created at the first one (Comm._data_group): a job without a data-path
+    collective never initialises RCCL.  backend="nccl" / "gloo" forces one group for everything."""
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_gpu = torch.cuda.is_available()
+    if os.environ.get("MPGAN_SHARE_DEVICE"):          # rehearsal of an N-rank job on a one-GPU box (no RCCL possible)
+        local_rank = 0
     device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(device)
@@ -96,11 +121,10 @@ def init_from_env(backend=None):
         return None, device
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
     if not dist.is_initialized():
+        to = datetime.timedelta(seconds=timeout_s)
         if backend == "nccl":
-            dist.init_process_group(backend, device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=to)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo", timeout=to)
     return Comm(), device

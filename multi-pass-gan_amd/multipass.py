@@ -86,6 +86,14 @@ class Generator(object):
     def params(self):
         return self.sess.vars.numpy()
 
+    def clone(self):
+        """the same network and weights with its own session (workspaces, packed weights): a second lane"""
+        g = Generator(self.kind, self.cfg, None, self.sess.prec, device=self.sess.device, prec_map=self.sess.prec_map)
+        for name, v in self.sess.vars.values.items():
+            g.sess.vars.values[name] = v
+        g.sess.vars.version += 1
+        return g
+
     def __call__(self, x, y=None):
         n = x.shape[0]
         feeds = {self.x: x.reshape(n, -1)}
@@ -192,28 +200,77 @@ def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_
     return final, v1
 
 
-def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
-    """The same two passes over a list of independent volumes, software-pipelined by one volume so that the
-    slab exchange of volume i (RCCL all-gather on its own stream) runs under pass 1 of volume i+1 and
-    pass 2 of volume i-1.  Same results as calling two_pass_4x per volume.  Returns the final volumes."""
-    comm = comm or LocalComm()
+def _two_pass_4x_steps(gen1, gen2, lows, finals, where, up_res, batch, comm, backend, vel_scale):
+    """generator over the software pipeline of two_pass_4x_batch: step i issues pass 1 of volume i, pass 2 of volume
+    i-1 and the final transpose of volume i-2; finals[where[k]] receives volume k"""
     n = len(lows)
-    g1, v1s, g2 = [None] * n, [None] * n, [None] * n
-    finals = [None] * n
+    g1, g2 = [None] * n, [None] * n
     for i in range(n + 2):
         if i < n:
             g1[i] = _pass1_4x(gen1, lows[i], up_res, batch, comm, backend, vel_scale)
         j = i - 1
         if 0 <= j < n:
-            v1s[j] = g1[j].wait()
+            v1 = g1[j].wait()
             g1[j] = None
-            g2[j] = _pass2_4x(gen2, lows[j], v1s[j], up_res, batch, comm, backend, vel_scale)
-            v1s[j] = None
+            g2[j] = _pass2_4x(gen2, lows[j], v1, up_res, batch, comm, backend, vel_scale)
+            del v1
         k = i - 2
         if 0 <= k < n:
-            finals[k] = backend.volume_transpose(g2[k].wait(), (1, 2, 0), cutoff=CUTOFF)
+            finals[where[k]] = backend.volume_transpose(g2[k].wait(), (1, 2, 0), cutoff=CUTOFF)
             g2[k] = None
+        yield
+
+
+def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0, lanes=None):
+    """The same two passes over a list of independent volumes, software-pipelined by one volume so that the
+    slab exchange of volume i (RCCL all-gather on its own stream) runs under pass 1 of volume i+1 and
+    pass 2 of volume i-1.  Same results as calling two_pass_4x per volume.  Returns the final volumes.
+
+    lanes: further (gen1, gen2) pairs (`Generator.clone()`: same weights, own workspaces).  The volumes are then dealt
+    round-robin to 1 + len(lanes) lanes, each issuing its pipeline on its own HIP stream, so that the launch tails and
+    the latency-bound small layers of one lane run under the matrix-bound layers of another."""
+    comm = comm or LocalComm()
+    n = len(lows)
+    finals = [None] * n
+    pairs = [(gen1, gen2)] + list(lanes or [])
+    if len(pairs) == 1 or n < 2 or not lows[0].is_cuda:
+        for _ in _two_pass_4x_steps(gen1, gen2, lows, finals, list(range(n)), up_res, batch, comm, backend, vel_scale):
+            pass
+        return finals
+    cur = torch.cuda.current_stream()
+    its = []
+    for li, (ga, gb) in enumerate(pairs):
+        idx = list(range(li, n, len(pairs)))
+        if not idx:
+            continue
+        st = _lane_stream(li)
+        st.wait_stream(cur)
+        its.append((st, _two_pass_4x_steps(ga, gb, [lows[i] for i in idx], finals, idx, up_res, batch, comm, backend,
+                                           vel_scale)))
+    live = list(its)
+    while live:                                   # one pipeline step per lane in turn: every stream stays fed
+        for item in list(live):
+            st, it = item
+            with torch.cuda.stream(st):
+                try:
+                    next(it)
+                except StopIteration:
+                    live.remove(item)
+    for st, _ in its:
+        cur.wait_stream(st)
+    for f in finals:
+        f.record_stream(cur)                      # allocated on a lane's stream, consumed on the caller's
     return finals
+
+
+_LANE_STREAMS = {}
+
+
+def _lane_stream(i):
+    dev = torch.cuda.current_device()
+    if (dev, i) not in _LANE_STREAMS:
+        _LANE_STREAMS[(dev, i)] = torch.cuda.Stream(device=dev)
+    return _LANE_STREAMS[(dev, i)]
 
 
 # ----------------------------------------------------------------------------

@@ -177,3 +177,39 @@ def test_architecture_tables(mpg):
     assert first == 32 and rows == ((8, (4, 4), 32, 64, 64), (4, (4, 4), 64, 128, 128), (2, (4, 4), 128, 384, 128))
     first, rows = arch.growing_disc_table(192, 192, 8, 3, False, 5)
     assert first == 24 and [r[1:] for r in rows] == [((5, 5), 24, 24, 48), ((5, 5), 48, 48, 96), ((5, 5), 96, 96, 96)]
+
+
+def test_no_packed_fp32_valu(mpg):
+    """The device code holds no packed-fp32 VALU instruction: a wave executing v_pk_fma_f32 next to an MFMA wave of
+    another stream was measured to return wrong sums on MI355X (profiles/r02/packed_fp32_mfma_interference.md), so the
+    library is built with -fno-slp-vectorize -fno-vectorize.  Disassembles the gfx950 code object of the built library."""
+    import os
+    import re
+    import subprocess
+    import tempfile
+    from mpgan_amd import _lib
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    bundler, objdump = os.path.join(llvm, "clang-offload-bundler"), os.path.join(llvm, "llvm-objdump")
+    asm = []
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", _lib.LIB_PATH, fat],
+                       check=True)
+        blob = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        starts = [m.start() for m in re.finditer(re.escape(magic), blob)]
+        assert starts, "no offload bundle in the library"
+        for k, a in enumerate(starts):                          # one bundle per translation unit
+            part = os.path.join(tmp, "part%d.bin" % k)
+            with open(part, "wb") as f:
+                f.write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            co = os.path.join(tmp, "dev%d.co" % k)
+            subprocess.run([bundler, "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            "--input=" + part, "--output=" + co], check=True)
+            asm.append(subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout)
+    asm = "\n".join(asm)
+    assert "v_mfma_f32_32x32x16_f16" in asm                     # it is the library's device code
+    packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
+    assert not packed, "%d packed-fp32 VALU instructions in libmpgan_hip.so" % len(packed)

@@ -98,6 +98,26 @@ def test_two_pass_4x_small(MP, mpg, prec, nch):
     assert np.array_equal(out2.cpu().numpy(), out.cpu().numpy())
 
 
+@pytest.mark.parametrize("nch", [1, 4])
+def test_two_pass_4x_batch_lanes(MP, mpg, nch):
+    """the volume pipeline on one, two and three HIP streams (cloned generators) returns the per-volume results bit for bit"""
+    from mpgan_amd.synthetic import synthetic_volume
+    sim, up = 8, 4
+    vs = 0.7 if nch > 1 else 1.0
+    lows = [_t(synthetic_volume(sim, nch, i)) for i in range(5)]
+    g1 = MP.Generator("gen_resnet", dict(tile_low=sim, up_res=up, channels=nch, upsampling_mode=2), None, 2, seed=5)
+    g2 = MP.Generator("gen_resnet", dict(tile_low=sim, up_res=up, channels=nch, upsampling_mode=1), None, 2, seed=6)
+    want = [MP.two_pass_4x(g1, g2, v, up, batch=8, vel_scale=vs)[0].cpu().numpy() for v in lows]
+    one = MP.two_pass_4x_batch(g1, g2, lows, up, batch=8, vel_scale=vs)
+    for lanes in (1, 2):
+        extra = [(g1.clone(), g2.clone()) for _ in range(lanes)]
+        for rep in range(2):                                   # the second call reuses the lanes' workspaces
+            got = MP.two_pass_4x_batch(g1, g2, lows, up, batch=8, vel_scale=vs, lanes=extra)
+            torch.cuda.synchronize()
+            for a, b, c in zip(got, want, one):
+                assert np.array_equal(a.cpu().numpy(), b) and np.array_equal(c.cpu().numpy(), b)
+
+
 @pytest.mark.parametrize("prec", [3, 2, 1])
 def test_two_pass_4x_c1_reduced(MP, mpg, prec):
     """BASELINE config C1 (4x two-pass, density only) at 16^3 -> 64^3, checked against the

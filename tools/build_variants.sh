@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../multi-pass-gan_amd/csrc"
 OUT=../../tools/variants
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I../../include -I."
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize -fno-vectorize -I../../include -I."
 build() {  # name, extra flags
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c mpgan_conv_mfma.hip -o $OUT/conv_$name.o
