@@ -248,6 +248,7 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(device)
+    MP.set_pass_lanes(args.lanes)
 
     n_vol = args.volumes_per_gpu * world
     cfg1 = dict(tile_low=SIM, up_res=UP, channels=1, upsampling_mode=2, batch_norm=True)

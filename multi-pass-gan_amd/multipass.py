@@ -12,6 +12,8 @@ Every pass shards over its slice axis: rank r of R evaluates slices
 pass (``dist.Comm``); with one rank this degenerates to the plain loop.
 The ``backend`` argument is the operator module (default: the HIP ``ops``).
 """
+import os
+
 import torch
 
 from . import graph as G
@@ -86,12 +88,26 @@ class Generator(object):
     def params(self):
         return self.sess.vars.numpy()
 
+    def clones(self, n):
+        """n further copies for the pass lanes, made once"""
+        have = self.__dict__.setdefault("_clones", [])
+        while len(have) < n:
+            have.append(self.clone())
+        for c in have:
+            if c._src_version != self.sess.vars.version:        # the weights were replaced (load): share the new tensors
+                for name, v in self.sess.vars.values.items():
+                    c.sess.vars.values[name] = v
+                c.sess.vars.version += 1
+                c._src_version = self.sess.vars.version
+        return have[:n]
+
     def clone(self):
         """the same network and weights with its own session (workspaces, packed weights): a second lane"""
         g = Generator(self.kind, self.cfg, None, self.sess.prec, device=self.sess.device, prec_map=self.sess.prec_map)
         for name, v in self.sess.vars.values.items():
             g.sess.vars.values[name] = v
         g.sess.vars.version += 1
+        g._src_version = self.sess.vars.version
         return g
 
     def __call__(self, x, y=None):
@@ -102,13 +118,42 @@ class Generator(object):
         return self.sess.run_device(self.sampler, feeds).reshape(n, self.high, self.high)
 
 
+# HIP streams the slice batches of one pass are dealt to (the batches are independent).  1 = the plain loop.
+PASS_LANES = [max(1, int(os.environ.get("MPG_LANES", "2")))]
+_NESTED = [False]          # set while two_pass_4x_batch runs whole volumes on lanes: no lanes inside lanes
+
+
+def set_pass_lanes(k):
+    PASS_LANES[0] = max(1, int(k))
+
+
 def _run_pass(gen, xs, ys, lo, hi, batch, out=None):
-    """the reference's per-pass sess.run loop (multipassGAN-out.py:443-447): slices [lo,hi) in batches"""
+    """the reference's per-pass sess.run loop (multipassGAN-out.py:443-447): slices [lo,hi) in batches.  With
+    PASS_LANES > 1 the batches alternate over that many HIP streams (clones of the generator: same weights, own
+    workspaces), so that the launch tails and latency-bound layers of one batch run under the next one's."""
+    nb = (hi - lo + batch - 1) // batch
+    lanes = 1 if (_NESTED[0] or not xs.is_cuda) else min(PASS_LANES[0], nb)
+    if lanes <= 1:
+        res = []
+        for j in range(lo, hi, batch):
+            k = min(j + batch, hi)
+            res.append(gen(xs[j:k], ys[j:k] if ys is not None else None))
+        return res[0] if len(res) == 1 else torch.cat(res, dim=0)
+    gens = [gen] + gen.clones(lanes - 1)
+    cur = torch.cuda.current_stream()
+    streams = [_lane_stream(i) for i in range(lanes)]
+    for st in streams:
+        st.wait_stream(cur)
     res = []
-    for j in range(lo, hi, batch):
+    for bi, j in enumerate(range(lo, hi, batch)):
         k = min(j + batch, hi)
-        res.append(gen(xs[j:k], ys[j:k] if ys is not None else None))
-    return res[0] if len(res) == 1 else torch.cat(res, dim=0)
+        with torch.cuda.stream(streams[bi % lanes]):
+            res.append(gens[bi % lanes](xs[j:k], ys[j:k] if ys is not None else None))
+    for st in streams:
+        cur.wait_stream(st)
+    for r in res:
+        r.record_stream(cur)
+    return torch.cat(res, dim=0)
 
 
 # ----------------------------------------------------------------------------
@@ -248,14 +293,18 @@ def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=op
         its.append((st, _two_pass_4x_steps(ga, gb, [lows[i] for i in idx], finals, idx, up_res, batch, comm, backend,
                                            vel_scale)))
     live = list(its)
-    while live:                                   # one pipeline step per lane in turn: every stream stays fed
-        for item in list(live):
-            st, it = item
-            with torch.cuda.stream(st):
-                try:
-                    next(it)
-                except StopIteration:
-                    live.remove(item)
+    _NESTED[0] = True
+    try:
+        while live:                               # one pipeline step per lane in turn: every stream stays fed
+            for item in list(live):
+                st, it = item
+                with torch.cuda.stream(st):
+                    try:
+                        next(it)
+                    except StopIteration:
+                        live.remove(item)
+    finally:
+        _NESTED[0] = False
     for st, _ in its:
         cur.wait_stream(st)
     for f in finals:

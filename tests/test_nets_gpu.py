@@ -118,6 +118,31 @@ def test_two_pass_4x_batch_lanes(MP, mpg, nch):
                 assert np.array_equal(a.cpu().numpy(), b) and np.array_equal(c.cpu().numpy(), b)
 
 
+def test_pass_lanes_reproduce_the_plain_loop(MP, mpg):
+    """the slice batches of a pass dealt to two or three HIP streams (multipass.PASS_LANES) give the plain loop's bits:
+    4x two passes on a 4-channel volume, 8x three networks"""
+    from mpgan_amd.synthetic import synthetic_volume
+    keep = MP.PASS_LANES[0]
+    try:
+        low4 = _t(synthetic_volume(8, 4, 3))
+        g1 = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=4, upsampling_mode=2), None, 2, seed=5)
+        g2 = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=4, upsampling_mode=1), None, 2, seed=6)
+        low8 = _t(synthetic_volume(4, 4, 2))
+        gens = [MP.Generator("growing_gen", dict(tile_low=4, up_res=8, channels=4, **NET_CFGS[n]), None, 2, seed=40 + i)
+                for i, n in enumerate(["net1", "net2", "net3"])]
+        res = {}
+        for lanes in (1, 2, 3):
+            MP.set_pass_lanes(lanes)
+            a, _ = MP.two_pass_4x(g1, g2, low4, 4, batch=4, vel_scale=0.7)
+            b = MP.multipass_8x(gens, low8, 8, batches=(4, 2, 2))
+            torch.cuda.synchronize()
+            res[lanes] = (a.cpu().numpy(), b.cpu().numpy())
+        for lanes in (2, 3):
+            assert np.array_equal(res[lanes][0], res[1][0]) and np.array_equal(res[lanes][1], res[1][1])
+    finally:
+        MP.set_pass_lanes(keep)
+
+
 @pytest.mark.parametrize("prec", [3, 2, 1])
 def test_two_pass_4x_c1_reduced(MP, mpg, prec):
     """BASELINE config C1 (4x two-pass, density only) at 16^3 -> 64^3, checked against the
