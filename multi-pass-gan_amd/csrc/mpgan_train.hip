@@ -155,9 +155,16 @@ __global__ void dgrad_kernel(const float* __restrict__ dy, const float* __restri
     dx[idx] = acc * wscale;
 }
 
+#ifndef MPG_BN_TWO_PASS
+#define MPG_BN_TWO_PASS 0
+#endif
 // ---------------------------------------------------------------- per-channel sums over pixels
 // MODE 0: sum x            MODE 1: sum (x - m)^2 with m = aux0[c] * inv_n
 // MODE 2: sum a, sum a*(x - mean)*invstd  (a = dy; two outputs)
+// MODE 3: sum (x - k), sum (x - k)^2 with k = aux0[c] * inv_n (the channel's mean over a leading sample of the pixels):
+//         both batch moments in ONE pass over x; with k within a fraction of sigma of the mean,
+//         var = E[(x-k)^2] - E[x-k]^2 loses nothing to cancellation (k = the first pixel's value did: a border pixel
+//         can sit many sigma away, and the gradients through the normalisation felt it)
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__ a, const float* __restrict__ x,
                                                        size_t npix, int c, int lanes, const float* __restrict__ aux0,
@@ -177,11 +184,13 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
         float m = 0.f, is = 0.f;
         if (MODE == 1) m = aux0[ch] * inv_n;
         if (MODE == 2) { m = aux0[ch]; is = rsqrtf(aux1[ch] + eps); }
+        if (MODE == 3) m = aux0[ch] * inv_n;
         for (size_t p = p_begin + row; p < p_end; p += ppi) {
             const float v = a[p * c + ch];
             if (MODE == 0) s0 += v;
             if (MODE == 1) { const float d = v - m; s0 = fmaf(d, d, s0); }
             if (MODE == 2) { s0 += v; s1 = fmaf(v, (x[p * c + ch] - m) * is, s1); }
+            if (MODE == 3) { const float d = v - m; s0 += d; s1 = fmaf(d, d, s1); }
         }
     }
     red0[tid] = s0;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
     if (row == 0 && ch < c) {
         for (int r = 1; r < ppi; ++r) { s0 += red0[r * lanes + lane]; s1 += red1[r * lanes + lane]; }
         atomicAdd(out0 + ch, s0);
-        if (MODE == 2) atomicAdd(out1 + ch, s1);
+        if (MODE == 2 || MODE == 3) atomicAdd(out1 + ch, s1);
     }
 }
 
@@ -213,10 +222,14 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
 // sums -> batch mean / biased variance, and the moving averages of tf.contrib batch_norm
 // (moving = decay * moving + (1 - decay) * batch) when their pointers are given
 __global__ void bn_finalize_kernel(float* mean, float* var, int c, float inv_n, float* moving_mean,
-                                   float* moving_var, float decay) {
+                                   float* moving_var, float decay, const float* __restrict__ shift, float shift_scale) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= c) return;
-    const float m = mean[i] * inv_n, v = var[i] * inv_n;
+    float m = mean[i] * inv_n, v = var[i] * inv_n;
+    if (shift != nullptr) {         // sums of (x - k) and (x - k)^2, k = shift * shift_scale
+        v = fmaxf(v - m * m, 0.f);
+        m += shift[i] * shift_scale;
+    }
     mean[i] = m;
     var[i] = v;
     if (moving_mean) moving_mean[i] = decay * moving_mean[i] + (1.f - decay) * m;
@@ -727,10 +740,21 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
     }
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
     const float inv_n = 1.f / (float)npix;
+#if MPG_BN_TWO_PASS
     launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, nullptr);
     launch_chan_sum<1>(s, x, nullptr, npix, c, batch_mean, nullptr, inv_n, 0.f, batch_var, nullptr);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
-                       moving_mean, moving_var, decay);
+                       moving_mean, moving_var, decay, (const float*)nullptr, 0.f);
+#else
+    // the first c floats of y hold the sample sums until bn_apply_kernel overwrites them (same stream)
+    const size_t ns = npix < 2048 ? npix : 2048;
+    e = mpg::zero_async(y, (size_t)c * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
+    launch_chan_sum<0>(s, x, nullptr, ns, c, nullptr, nullptr, 0.f, 0.f, y, nullptr);
+    launch_chan_sum<3>(s, x, nullptr, npix, c, y, nullptr, 1.f / (float)ns, 0.f, batch_mean, batch_var);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
+                       moving_mean, moving_var, decay, y, 1.f / (float)ns);
+#endif
     const size_t total = npix * c;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
                        gamma, beta, eps, act, leak, y);

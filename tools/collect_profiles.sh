@@ -8,9 +8,15 @@ mkdir -p $O
 export TMPDIR=/tmp
 python bench.py > $O/bench.json 2> $O/bench.err || echo "bench rc $?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-prec > $O/prof_bench.log 2>&1
+# the per-layer table needs the launches of one generator call in order: one lane
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench_1lane -- python bench.py --lanes 1 --steps 2 --warmup 1 --no-cpu-baseline --no-second-prec > $O/prof_bench_1lane.log 2>&1
+python tools/layer_table.py $(ls $O/prof_bench_1lane/*/*_kernel_trace.csv | tail -1) > $O/per_layer_1lane.txt 2>&1
+python bench.py --lanes 1 --no-cpu-baseline > $O/bench_1lane.json 2> $O/bench_1lane.err || echo "bench 1 lane rc $?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python tools/roofline_probe.py 2 6 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python tools/roofline_probe.py 2 6 > $O/pmc_write.log 2>&1
 python tools/probe_8x.py 2 3 > $O/c4_probe.txt 2>&1
+MPG_LANES=1 python tools/probe_8x.py 2 3 > $O/c4_probe_1lane.txt 2>&1
+python tools/probe_small.py > $O/small_layers.txt 2>&1
 python tools/probe_transpose.py > $O/hbm_kernels.md 2>&1
 python tools/probe_split.py > $O/split.log 2>&1
 python bench_train.py > $O/bt_c3.json 2> $O/bt_c3.err || true
