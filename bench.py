@@ -104,7 +104,7 @@ def _time_events(fn, iters, device, torch):
     return e0.elapsed_time(e1) / iters
 
 
-def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20):
+def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pass=None):
     """The dominant launch: resBlock 1's B conv (5x5 128->128 plus its 1x1 8->128 shortcut as a second
     K-segment, multipassGAN-4x.py:561) on one batch of 8 slices of 256^2.  Timed twice with events on the
     launch stream: on the activations the pipeline itself produced for `x_batch` (tapped from the running
@@ -118,7 +118,19 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20):
     sess.tap, sess.tapped = "g_cB1/", None
     gen2(x_batch)
     call = sess.tapped
-    sess.tap = sess.tapped = None
+    sess.tapped = None
+    # in the pipeline: every launch of this layer during one more pass over a volume (single stream, so that no other
+    # lane's kernels share the CUs), bracketed by HIP events on the launch stream
+    ms_inpipe = n_inpipe = None
+    if pipeline_pass is not None:
+        sess.tap_events = []
+        pipeline_pass()
+        torch.cuda.synchronize(device)
+        t = [a.elapsed_time(b) for a, b in sess.tap_events]
+        sess.tap_events = None
+        if t:
+            ms_inpipe, n_inpipe = sum(t) / len(t), len(t)
+    sess.tap = None
     ms_pipe = None
     if call is not None:
         for _ in range(3):
@@ -141,7 +153,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20):
     for _ in range(3):
         launch()
     ms_rand = _time_events(launch, iters, device, torch)
-    ms = ms_pipe if ms_pipe is not None else ms_rand
+    ms = ms_inpipe if ms_inpipe is not None else (ms_pipe if ms_pipe is not None else ms_rand)
     achieved = flops / (ms * 1e-3) / 1e12
     # HBM bytes per launch of this very launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     # per MI355X_MICROARCH.md + WRITE_SIZE); null for other modes
@@ -163,7 +175,10 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20):
         "traffic": traffic,
         "traffic_source": src,
         "launch_ms": round(ms, 4),
-        "launch_ms_data": "activations of pass 2, slices 120..127 of volume 0, taken from the running pipeline" if ms_pipe is not None else "dense random",
+        "launch_ms_data": ("mean over the %d launches of this layer in pass 2 of volume 0, HIP events around each launch on its "
+                           "stream inside the running pipeline (one lane)" % n_inpipe) if ms_inpipe is not None else
+                          ("replay of one launch on activations taken from the pipeline" if ms_pipe is not None else "dense random"),
+        "launch_ms_replay": round(ms_pipe, 4) if ms_pipe is not None else None,
         "launch_ms_random": round(ms_rand, 4),
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 fp8 (MX, K=64)", 1: "1 fp16"}[prec],
@@ -355,7 +370,14 @@ def main(argv=None):
         gpu_runs["f16x3"] = (f3.cpu().numpy(), v3.cpu().numpy())
         del f3, v3
     x_batch = MP.ops.volume_transpose(v0, (2, 0, 1)).reshape(S, S, S, 1)[120:128].contiguous()
-    result["roofline"] = dominant_kernel_roofline(g2, x_batch, device, args.prec)
+    def one_more_pass():
+        MP.set_pass_lanes(1)
+        try:
+            MP.two_pass_4x(g1, g2, lows[0], UP, batch=args.slice_batch)
+        finally:
+            MP.set_pass_lanes(args.lanes)
+
+    result["roofline"] = dominant_kernel_roofline(g2, x_batch, device, args.prec, pipeline_pass=one_more_pass)
     ok = True
     if world == 1 and not args.no_cpu_baseline:
         base, parity, idx = cpu_baseline_and_parity(g1.params(), g2.params(), lows_np[0], gpu_runs,

@@ -263,12 +263,15 @@ int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, flo
 int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
                      const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
                      float* batch_var, float* moving_mean, float* moving_var, float decay);
-/* gradient of the normalisation above (dy is taken before the activation) */
+/* gradient of the normalisation above (dy is taken before the activation).  amax (may be NULL) receives max |dx|:
+ * the data- and weight-gradient convolutions that consume dx scale it by a power of two before the fp16 split
+ * (mpg_absmax would re-read the tensor for it). */
 int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
                      const float* batch_mean, const float* batch_var, const float* gamma, float eps,
-                     float* dx, float* dgamma, float* dbeta);
-/* dx = dy * act'(.) written through the activation OUTPUT y (relu, lrelu GAN.py:733-737, tanh) */
-int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak, float* dx);
+                     float* dx, float* dgamma, float* dbeta, float* amax);
+/* dx = dy * act'(.) written through the activation OUTPUT y (relu, lrelu GAN.py:733-737, tanh); amax as above */
+int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak, float* dx,
+                float* amax);
 /* gradient of GAN.pixel_norm (GAN.py:472-474) */
 int mpg_pixel_norm_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c, float eps,
                        float* dx);

@@ -247,32 +247,53 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, size_t total, int c
     y[idx] = mpg::apply_act(v, act, leak);
 }
 
+// running max |v| into *out (float bits of a non-negative value; order like unsigned ints): one wave reduction, and the
+// atomic only when the wave's maximum beats what is already there (after the first waves almost never)
+__device__ __forceinline__ void wave_absmax_to(float v, unsigned int* __restrict__ out) {
+    float m = fabsf(v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(m);
+        if (bits > *reinterpret_cast<volatile unsigned int*>(out)) atomicMax(out, bits);
+    }
+}
+
 // dx = gamma * invstd * (dy - dbeta/N - xhat * dgamma/N)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, size_t total, int c,
                                     const float* __restrict__ mean, const float* __restrict__ var,
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, float eps, float inv_n, float* __restrict__ dx) {
+                                    const float* __restrict__ dbeta, float eps, float inv_n, float* __restrict__ dx,
+                                    unsigned int* __restrict__ amax) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (idx >= total) return;
-    const int ch = idx % c;
-    const float is = rsqrtf(var[ch] + eps);
-    const float xh = (x[idx] - mean[ch]) * is;
-    dx[idx] = gamma[ch] * is * (dy[idx] - dbeta[ch] * inv_n - xh * dgamma[ch] * inv_n);
+    float v = 0.f;
+    if (idx < total) {
+        const int ch = idx % c;
+        const float is = rsqrtf(var[ch] + eps);
+        const float xh = (x[idx] - mean[ch]) * is;
+        v = gamma[ch] * is * (dy[idx] - dbeta[ch] * inv_n - xh * dgamma[ch] * inv_n);
+        dx[idx] = v;
+    }
+    if (amax != nullptr) wave_absmax_to(v, amax);
 }
 
 // ---------------------------------------------------------------- elementwise backward
 // derivative expressed through the activation OUTPUT y (relu: y>0; lrelu: slope 1 / leak by sign of y,
 // 0.5(1+leak) at 0 as tf.abs has a zero gradient there, GAN.py:733-737; tanh: 1 - y^2)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int act,
-                               float leak, float* __restrict__ dx) {
+                               float leak, float* __restrict__ dx, unsigned int* __restrict__ amax) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (idx >= n) return;
-    const float o = y[idx];
-    float d = 1.f;
-    if (act == MPG_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
-    else if (act == MPG_ACT_LRELU) d = o > 0.f ? 1.f : (o < 0.f ? leak : 0.5f * (1.f + leak));
-    else if (act == MPG_ACT_TANH) d = 1.f - o * o;
-    dx[idx] = dy[idx] * d;
+    float v = 0.f;
+    if (idx < n) {
+        const float o = y[idx];
+        float d = 1.f;
+        if (act == MPG_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
+        else if (act == MPG_ACT_LRELU) d = o > 0.f ? 1.f : (o < 0.f ? leak : 0.5f * (1.f + leak));
+        else if (act == MPG_ACT_TANH) d = 1.f - o * o;
+        v = dy[idx] * d;
+        dx[idx] = v;
+    }
+    if (amax != nullptr) wave_absmax_to(v, amax);
 }
 
 // y = x * r, r = rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)); `lanes` consecutive lanes per pixel
@@ -763,7 +784,7 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
 
 extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
                                 const float* batch_mean, const float* batch_var, const float* gamma, float eps,
-                                float* dx, float* dgamma, float* dbeta) {
+                                float* dx, float* dgamma, float* dbeta, float* amax) {
     MPG_REQUIRE(dy && x && batch_mean && batch_var && gamma && dx && dgamma && dbeta,
                 "mpg_bn_train_bwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_bwd: bad shape");
@@ -775,20 +796,26 @@ extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const floa
         e = mpg::zero_async(dgamma, (size_t)c * sizeof(float), s);
         if (e == hipSuccess) e = mpg::zero_async(dbeta, (size_t)c * sizeof(float), s);
     }
+    if (e == hipSuccess && amax != nullptr) e = mpg::zero_async(amax, sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
     launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
     const size_t total = npix * c;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, dy, x, total, c, batch_mean,
-                       batch_var, gamma, dgamma, dbeta, eps, 1.f / (float)npix, dx);
+                       batch_var, gamma, dgamma, dbeta, eps, 1.f / (float)npix, dx, (unsigned int*)amax);
     MPG_LAUNCH_CHECK("bn_train_bwd");
 }
 
 extern "C" int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak,
-                           float* dx) {
+                           float* dx, float* amax) {
     MPG_REQUIRE(dy && y && dx, "mpg_act_bwd: null pointer");
     MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_act_bwd: bad activation %d", act);
+    if (amax != nullptr) {
+        hipError_t e = mpg::zero_async(amax, sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) return mpg::hip_check(e, "mpg_act_bwd: zero");
+    }
     if (n == 0) return MPG_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx,
+                       (unsigned int*)amax);
     MPG_LAUNCH_CHECK("act_bwd_kernel");
 }
 

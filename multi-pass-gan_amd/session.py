@@ -122,6 +122,7 @@ class Session(object):
         # so that bench.py can re-issue exactly that launch on exactly those activations
         self.tap = None
         self.tapped = None
+        self.tap_events = None     # a list: every tapped launch is bracketed by a (start, end) pair of timing events on its stream
 
     # ------------------------------------------------------------------ public
     def run(self, fetches, feed_dict=None):
@@ -358,8 +359,15 @@ class Session(object):
                 self.tapped = dict(segments=seg_objs, out_hw=out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn,
                                    pn_eps=pn_eps, post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"],
                                    want_g8c=emit["g8c"])
+            timed = self.tap is not None and self.tap_events is not None and self.tap in lead
+            if timed:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
                                    post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"], want_g8c=emit["g8c"])
+            if timed:
+                ev[1].record()
+                self.tap_events.append(ev)
             res = list(res) if isinstance(res, tuple) else [res]
             out = {"f32": None, "g8": {}}
             if emit["f32"]:

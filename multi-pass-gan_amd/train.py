@@ -90,14 +90,24 @@ class ConvLayerFn(torch.autograd.Function):
             x, w, y = ctx.saved_tensors
         kh, kw, cin, cout = w.shape
         d = dy.contiguous()
+        # max |d| (the power-of-two scale of both gradient convolutions) comes out of the kernel that produces d
+        need_amax = stride == (1, 1) and not cfg.get("fc")
+        d_amax = None
         if act is not None:
-            d = train_ops.act_bwd(d, y, act, leak)
+            if need_amax and not ctx.bn:
+                d, d_amax = train_ops.act_bwd(d, y, act, leak, want_amax=True)
+            else:
+                d = train_ops.act_bwd(d, y, act, leak)
         dgamma = dbeta = None
         if ctx.bn:
-            d, dgamma, dbeta = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"])
+            if need_amax:
+                d, dgamma, dbeta, d_amax = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"], want_amax=True)
+            else:
+                d, dgamma, dbeta = train_ops.bn_train_bwd(d, lin, mean, var, gamma, cfg["eps"])
         db = train_ops.channel_sum(d) if ctx.has_bias else None
         dw = None
-        d_amax = ops.absmax(d) if (stride == (1, 1) and not cfg.get("fc")) else None     # shared by both gradients
+        if need_amax and d_amax is None:
+            d_amax = ops.absmax(d)                                                      # shared by both gradients
         if ctx.needs_input_grad[1]:
             if train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and cfg.get("wgrad_mfma", True):
                 dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax)

@@ -101,26 +101,30 @@ def bn_train_fwd(x, gamma, beta, eps=1e-3, act=None, leak=0.2, moving_mean=None,
     return y, mean, var
 
 
-def bn_train_bwd(dy, x, mean, var, gamma, eps=1e-3):
-    """-> (dx, dgamma, dbeta); dy is the gradient at the normalised (pre-activation) output"""
+def bn_train_bwd(dy, x, mean, var, gamma, eps=1e-3, want_amax=False):
+    """-> (dx, dgamma, dbeta [, max |dx| as a 0-dim tensor]); dy is the gradient at the normalised (pre-activation) output"""
     lib = _lib.load()
     dy, x = _cont(dy, "dy"), _cont(x, "x")
     c = x.shape[-1]
     dx = torch.empty_like(x)
     dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
     dgamma, dbeta = dgb[0], dgb[1]
+    amax = torch.empty((), dtype=torch.float32, device=x.device) if want_amax else None
     _lib.check(lib.mpg_bn_train_bwd(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, _ptr(mean), _ptr(var),
-                                    _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta)),
-               "mpg_bn_train_bwd")
-    return dx, dgamma, dbeta
+                                    _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                    _ptr(amax) if want_amax else None), "mpg_bn_train_bwd")
+    return (dx, dgamma, dbeta, amax) if want_amax else (dx, dgamma, dbeta)
 
 
-def act_bwd(dy, y, act, leak=0.2):
+def act_bwd(dy, y, act, leak=0.2, want_amax=False):
+    """dx = dy * act'(.) [, max |dx| as a 0-dim tensor]"""
     lib = _lib.load()
     dy, y = _cont(dy, "dy"), _cont(y, "y")
     dx = torch.empty_like(dy)
-    _lib.check(lib.mpg_act_bwd(_stream(), _ptr(dy), _ptr(y), dy.numel(), _lib.act_id(act), leak, _ptr(dx)), "mpg_act_bwd")
-    return dx
+    amax = torch.empty((), dtype=torch.float32, device=dy.device) if want_amax else None
+    _lib.check(lib.mpg_act_bwd(_stream(), _ptr(dy), _ptr(y), dy.numel(), _lib.act_id(act), leak, _ptr(dx),
+                               _ptr(amax) if want_amax else None), "mpg_act_bwd")
+    return (dx, amax) if want_amax else dx
 
 
 def pixel_norm_bwd(dy, x, eps=1e-8):
