@@ -237,11 +237,15 @@ int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, i
 /* The same weight gradient on the matrix cores for stride-1 filters (kh <= 7, kw in 1,3,4,5):
  * x and dy are rewritten channel-major in fp16 (hi + lo planes, power-of-two scaled) inside
  * `workspace` (>= mpg_conv2d_wgrad_mfma_ws_bytes, 256-byte aligned), then contracted over pixels
- * with v_mfma_f32_32x32x16_f16.  prec MPG_PREC_F16X3 (three products, fp32-grade) or MPG_PREC_F16X1. */
+ * with v_mfma_f32_32x32x16_f16.  prec MPG_PREC_F16X3 (three products, fp32-grade) or MPG_PREC_F16X1.
+ * dy_amax / x_amax (device scalars, may be NULL): max |dy| / max |x| when the caller already has them (the kernel that
+ * produced dy returns it; a forward activation needs no scaling: pass a scalar holding 256.0f = scale 1) -- without
+ * them each costs a reduction pass over its tensor. */
 size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout);
 int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
                           const float* dy, int cout, int kh, int kw, float wscale, int prec,
-                          void* workspace, size_t workspace_bytes, const float* dy_amax, float* dw);
+                          void* workspace, size_t workspace_bytes, const float* dy_amax, const float* x_amax,
+                          float* dw);
 /* dy_amax: NULL, or a device float holding max |dy| already computed with mpg_absmax */
 /* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
  * convs, multipassGAN-4x.py:607-614).  The filter is passed with its channel axes swapped,

@@ -104,6 +104,9 @@ constexpr int x_units(int kw, int cotw) { return kw * cotw > 12 ? 6 : 10; }
 template <int KW, int COTW, int PREC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // equal output-channel windows of one layer run as one launch (blockIdx.y): their blocks are co-resident and share
+    // the x rows through L2 instead of streaming them from memory once per window
+    const int co_base = a.co0 + blockIdx.y * a.cout;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     // XCD-aware order: the kh blocks of one row range land on the same XCD (shared L2)
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
                 const int ch = rr / nplane, pln = rr % nplane;
                 const int px = x0 + off * 8;
                 if (ch < a.cout && px < a.wp)
-                    v = *reinterpret_cast<const u32x4*>(a.dp + ((drow + a.co0 + ch) * 2 + pln) * a.wp + px);
+                    v = *reinterpret_cast<const u32x4*>(a.dp + ((drow + co_base + ch) * 2 + pln) * a.wp + px);
             }
             dreg[i] = v;
         }
@@ -272,19 +275,19 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
                 const int ci = cit * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
                 const float val = acc[kx][t][v];
                 if (ci < a.cin && val != 0.f)
-                    atomicAdd(a.dw + ((size_t)(ky * KW + kx) * a.cin_total + a.ci0 + ci) * a.cout_total + a.co0 + co,
+                    atomicAdd(a.dw + ((size_t)(ky * KW + kx) * a.cin_total + a.ci0 + ci) * a.cout_total + co_base + co,
                               val * unscale);
             }
         }
 }
 
 template <int KW, int COTW, int PREC>
-hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes) {
+hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes, int windows) {
     auto kern = wgrad_mfma_kernel<KW, COTW, PREC>;
     static int lds_limit[64] = {0};
     hipError_t e = mpg::ensure_dyn_lds((const void*)kern, 160 * 1024, lds_limit);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks, windows), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -311,7 +314,8 @@ extern "C" size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, i
 
 extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
                                      const float* dy, int cout, int kh, int kw, float wscale, int prec,
-                                     void* workspace, size_t workspace_bytes, const float* dy_amax, float* dw) {
+                                     void* workspace, size_t workspace_bytes, const float* dy_amax, const float* x_amax,
+                                     float* dw) {
     MPG_REQUIRE(x && dy && dw && workspace, "mpg_conv2d_wgrad_mfma: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_wgrad_mfma: bad shape");
     MPG_REQUIRE(kh >= 1 && kh <= 7 && (kw == 1 || kw == 3 || kw == 4 || kw == 5),
@@ -330,7 +334,11 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
     auto am_grid = [](size_t n) { const size_t b = (n + BLK * 16 - 1) / (BLK * 16); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
-    hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
+    if (x_amax != nullptr)       // e.g. a forward activation whose scale the caller fixes (no reduction pass over x)
+        e = hipMemcpyAsync(amax, x_amax, sizeof(float), hipMemcpyDeviceToDevice, s);
+    else
+        hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: copy of x_amax");
     if (dy_amax != nullptr)      // the caller already reduced max |dy| (it scales the data gradient with it too)
         e = hipMemcpyAsync(amax + 1, dy_amax, sizeof(float), hipMemcpyDeviceToDevice, s);
     else
@@ -344,8 +352,9 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     // a wave keeps KW * COTW accumulator tiles of 16 registers in the 256 AccVGPRs: 16 tiles at most, so a
     // 5-wide filter row takes 64 output channels per launch (x is then staged twice, from L2)
     const int co_step = kw >= 5 ? 64 : 128;
+    const bool merged = cout > co_step && cout % co_step == 0;     // equal windows: one launch, windows on grid.y
     for (int ci0 = 0; ci0 < cin; ci0 += 128)
-        for (int co0 = 0; co0 < cout; co0 += co_step) {
+        for (int co0 = 0; co0 < (merged ? 1 : cout); co0 += co_step) {
             WgArgs a;
             a.xp = xp; a.dp = dp; a.amax = amax; a.dw = dw;
             a.n = n; a.h = h; a.w = w; a.wp = wp;
@@ -384,10 +393,11 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
             a.rows_per_split = (rows + nsplit - 1) / nsplit;
             a.nsplit = (rows + a.rows_per_split - 1) / a.rows_per_split;
             const int blocks = ((a.nsplit + 7) / 8) * 8 * kh;
+            const int windows = merged ? cout / co_step : 1;
             hipError_t le = hipErrorInvalidValue;
 #define MPG_WGM(K, C)                                                                        \
     if (kw == K && cotw == C)                                                                \
-        le = prec == MPG_PREC_F16X3 ? launch<K, C, 3>(s, a, blocks, lds) : launch<K, C, 1>(s, a, blocks, lds)
+        le = prec == MPG_PREC_F16X3 ? launch<K, C, 3>(s, a, blocks, lds, windows) : launch<K, C, 1>(s, a, blocks, lds, windows)
             MPG_WGM(1, 1); MPG_WGM(1, 2); MPG_WGM(1, 4); MPG_WGM(3, 1); MPG_WGM(3, 2); MPG_WGM(3, 4);
             MPG_WGM(4, 1); MPG_WGM(4, 2); MPG_WGM(4, 4); MPG_WGM(5, 1); MPG_WGM(5, 2);
 #undef MPG_WGM

@@ -110,7 +110,9 @@ class ConvLayerFn(torch.autograd.Function):
             d_amax = ops.absmax(d)                                                      # shared by both gradients
         if ctx.needs_input_grad[1]:
             if train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and cfg.get("wgrad_mfma", True):
-                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax)
+                # x is the layer's forward input (an activation): split unscaled, no abs-max pass over it
+                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax,
+                                                 train_ops.unit_amax(x.device))
             else:
                 dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale)
         dx = None

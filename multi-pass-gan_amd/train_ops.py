@@ -29,7 +29,19 @@ def wgrad_mfma_ok(kh, kw, stride):
     return tuple(stride) == (1, 1) and 1 <= kh <= 7 and kw in (1, 3, 4, 5)
 
 
-def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, dy_amax=None):
+_UNIT = {}
+
+
+def unit_amax(device):
+    """device scalar 256.0: as `x_amax` it selects scale 1 (mpg::pow2_scale brings the maximum into [2^8, 2^9)) -- for
+    forward activations, which are O(1) and need no scaling ahead of the fp16 hi/lo split"""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.full((), 256.0, dtype=torch.float32, device=device)
+    return _UNIT[key]
+
+
+def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, dy_amax=None, x_amax=None):
     """stride-1 weight gradient on the matrix cores (mpg_conv2d_wgrad_mfma)"""
     lib = _lib.load()
     x, dy = _cont(x, "x"), _cont(dy, "dy")
@@ -41,7 +53,7 @@ def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, dy_amax=N
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     dw = torch.empty((kh, kw, cin, cout), dtype=torch.float32, device=x.device)
     _lib.check(lib.mpg_conv2d_wgrad_mfma(_stream(), _ptr(x), n, h, w, cin, _ptr(dy), cout, kh, kw, float(wscale), prec,
-                                         _ptr(ws), nbytes, _ptr(dy_amax), _ptr(dw)), "mpg_conv2d_wgrad_mfma")
+                                         _ptr(ws), nbytes, _ptr(dy_amax), _ptr(x_amax), _ptr(dw)), "mpg_conv2d_wgrad_mfma")
     return dw
 
 

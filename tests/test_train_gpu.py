@@ -98,6 +98,11 @@ def test_conv_wgrad_mfma(case, prec):
     dw = train_ops.conv2d_wgrad_mfma(dev(x), dev(dy), k, k, wscale, prec).cpu().numpy()
     assert dw.shape == dw_ref.shape
     assert rel(dw, dw_ref) < (2e-6 if prec == 3 else 2e-3)
+    # the training step's call: max |dy| handed in by the producer of dy, x (an O(1) activation) split unscaled
+    from mpgan_amd import ops
+    dyd = dev(dy)
+    dw2 = train_ops.conv2d_wgrad_mfma(dev(x), dyd, k, k, wscale, prec, ops.absmax(dyd), train_ops.unit_amax(dyd.device))
+    assert rel(dw2.cpu().numpy(), dw_ref) < (2e-6 if prec == 3 else 2e-3)
 
 
 def test_conv_wgrad_mfma_zero_and_constant():

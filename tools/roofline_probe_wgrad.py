@@ -11,12 +11,19 @@ import torch
 import mpgan_amd  # noqa: F401
 from mpgan_amd import train_ops
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+iters = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 4
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(1)
 x = torch.randn((16, 256, 256, 128), device=dev, generator=g).relu_()
 dy = torch.randn((16, 256, 256, 128), device=dev, generator=g) * 1e-4
+# as the training step calls it (train.ConvLayerFn.backward): max |dy| comes from the kernel that produced dy, x is a forward
+# activation (split unscaled); `--standalone` reduces both inside the call, as round 1 measured it
+standalone = "--standalone" in sys.argv
+from mpgan_amd import ops
+dy_amax = None if standalone else ops.absmax(dy)
+x_amax = None if standalone else train_ops.unit_amax(x.device)
+torch.cuda.synchronize()
 for _ in range(iters):
-    train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3)
+    train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3, dy_amax, x_amax)
 torch.cuda.synchronize()
 print("done")
