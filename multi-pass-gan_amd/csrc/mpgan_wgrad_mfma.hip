@@ -89,6 +89,7 @@ struct WgArgs {
     float* dw;               // [kh][kw][cin_total][cout_total]
     int n, h, w, wp;
     int cin_total, cout_total, ci0, co0, cin, cout;   // channel window of this launch (cin, cout <= 128)
+    int windows;                                       // equal cout windows handled by this launch (>= 1)
     int kh, pt, pl;
     int cit, cog, ks;        // waves = cit * cog * ks = 4
     int chunk;               // pixels per chunk = 32 * ks
@@ -104,13 +105,15 @@ constexpr int x_units(int kw, int cotw) { return kw * cotw > 12 ? 6 : 10; }
 template <int KW, int COTW, int PREC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    // equal output-channel windows of one layer run as one launch (blockIdx.y): their blocks are co-resident and share
-    // the x rows through L2 instead of streaming them from memory once per window
-    const int co_base = a.co0 + blockIdx.y * a.cout;
+    // equal output-channel windows of one layer run as one launch: linear block id = (jj * windows + window) * 8 + xcd, so
+    // the windows of one row range are dispatched together and to the same XCD, and share the x rows through its L2
+    // instead of streaming them from memory once per window
+    const int nwin = a.windows;
+    const int co_base = a.co0 + ((blockIdx.x / 8) % nwin) * a.cout;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
     // XCD-aware order: the kh blocks of one row range land on the same XCD (shared L2)
-    const int xcd = blockIdx.x % 8, jj = blockIdx.x / 8;
+    const int xcd = blockIdx.x % 8, jj = blockIdx.x / (8 * nwin);
     const int ky = jj % a.kh;
     const int split = (jj / a.kh) * 8 + xcd;
     if (split >= a.nsplit) return;
@@ -287,7 +290,7 @@ hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes, 
     static int lds_limit[64] = {0};
     hipError_t e = mpg::ensure_dyn_lds((const void*)kern, 160 * 1024, lds_limit);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks, windows), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks * windows), dim3(256), lds_bytes, s, a);
     return hipGetLastError();
 }
 
@@ -394,6 +397,7 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
             a.nsplit = (rows + a.rows_per_split - 1) / a.rows_per_split;
             const int blocks = ((a.nsplit + 7) / 8) * 8 * kh;
             const int windows = merged ? cout / co_step : 1;
+            a.windows = windows;
             hipError_t le = hipErrorInvalidValue;
 #define MPG_WGM(K, C)                                                                        \
     if (kw == K && cotw == C)                                                                \

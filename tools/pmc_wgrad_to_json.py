@@ -9,7 +9,8 @@ def table(d, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        k = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        k = k.split("(")[0] if not k.startswith("_Z") else k
         e = by.setdefault(k, {})
         e[r["Dispatch_Id"]] = e.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     return {k: (sum(v.values()), len(v)) for k, v in by.items()}
