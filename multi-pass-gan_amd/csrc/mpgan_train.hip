@@ -161,10 +161,15 @@ __global__ void dgrad_kernel(const float* __restrict__ dy, const float* __restri
 // ---------------------------------------------------------------- per-channel sums over pixels
 // MODE 0: sum x            MODE 1: sum (x - m)^2 with m = aux0[c] * inv_n
 // MODE 2: sum a, sum a*(x - mean)*invstd  (a = dy; two outputs)
-// MODE 3: sum (x - k), sum (x - k)^2 with k = aux0[c] * inv_n (the channel's mean over a leading sample of the pixels):
-//         both batch moments in ONE pass over x; with k within a fraction of sigma of the mean,
+// MODE 3: sum (x - k), sum (x - k)^2 with k = bn_shift(x, ch): the channel's mean over four pixels spread through the
+//         batch: both batch moments in ONE pass over x.  With k within a few sigma of the mean,
 //         var = E[(x-k)^2] - E[x-k]^2 loses nothing to cancellation (k = the first pixel's value did: a border pixel
 //         can sit many sigma away, and the gradients through the normalisation felt it)
+__device__ __forceinline__ float bn_shift(const float* __restrict__ x, size_t npix, int c, int ch) {
+    const size_t q = npix >> 3;
+    return 0.25f * (x[q * c + ch] + x[3 * q * c + ch] + x[5 * q * c + ch] + x[7 * q * c + ch]);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__ a, const float* __restrict__ x,
                                                        size_t npix, int c, int lanes, const float* __restrict__ aux0,
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
         float m = 0.f, is = 0.f;
         if (MODE == 1) m = aux0[ch] * inv_n;
         if (MODE == 2) { m = aux0[ch]; is = rsqrtf(aux1[ch] + eps); }
-        if (MODE == 3) m = aux0[ch] * inv_n;
+        if (MODE == 3) m = bn_shift(a, npix, c, ch);
         for (size_t p = p_begin + row; p < p_end; p += ppi) {
             const float v = a[p * c + ch];
             if (MODE == 0) s0 += v;
@@ -222,13 +227,13 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
 // sums -> batch mean / biased variance, and the moving averages of tf.contrib batch_norm
 // (moving = decay * moving + (1 - decay) * batch) when their pointers are given
 __global__ void bn_finalize_kernel(float* mean, float* var, int c, float inv_n, float* moving_mean,
-                                   float* moving_var, float decay, const float* __restrict__ shift, float shift_scale) {
+                                   float* moving_var, float decay, const float* __restrict__ shift, size_t shift_npix) {
     const int i = blockIdx.x * BLK + threadIdx.x;
     if (i >= c) return;
     float m = mean[i] * inv_n, v = var[i] * inv_n;
-    if (shift != nullptr) {         // sums of (x - k) and (x - k)^2, k = shift * shift_scale
+    if (shift != nullptr) {         // sums of (x - k) and (x - k)^2 over the `shift` tensor of shift_npix pixels
         v = fmaxf(v - m * m, 0.f);
-        m += shift[i] * shift_scale;
+        m += bn_shift(shift, shift_npix, c, i);
     }
     mean[i] = m;
     var[i] = v;
@@ -765,16 +770,11 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
     launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, nullptr);
     launch_chan_sum<1>(s, x, nullptr, npix, c, batch_mean, nullptr, inv_n, 0.f, batch_var, nullptr);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
-                       moving_mean, moving_var, decay, (const float*)nullptr, 0.f);
+                       moving_mean, moving_var, decay, (const float*)nullptr, (size_t)0);
 #else
-    // the first c floats of y hold the sample sums until bn_apply_kernel overwrites them (same stream)
-    const size_t ns = npix < 2048 ? npix : 2048;
-    e = mpg::zero_async(y, (size_t)c * sizeof(float), s);
-    if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_fwd: memset");
-    launch_chan_sum<0>(s, x, nullptr, ns, c, nullptr, nullptr, 0.f, 0.f, y, nullptr);
-    launch_chan_sum<3>(s, x, nullptr, npix, c, y, nullptr, 1.f / (float)ns, 0.f, batch_mean, batch_var);
+    launch_chan_sum<3>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, batch_var);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
-                       moving_mean, moving_var, decay, y, 1.f / (float)ns);
+                       moving_mean, moving_var, decay, x, npix);
 #endif
     const size_t total = npix * c;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,

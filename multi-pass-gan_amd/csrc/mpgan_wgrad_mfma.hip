@@ -49,6 +49,11 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t n, unsigned in
     if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0]));   // non-negative floats order like their bit patterns
 }
 
+__global__ void amax_init_kernel(float* __restrict__ amax, const float* __restrict__ x_amax, const float* __restrict__ dy_amax) {
+    const int i = threadIdx.x;
+    if (i < 64) amax[i] = i == 0 ? (x_amax ? *x_amax : 0.f) : (i == 1 ? (dy_amax ? *dy_amax : 0.f) : 0.f);
+}
+
 // fp32 NHWC -> P16.  block: one image row, 64 pixels, 64 channels through an LDS transpose.
 __global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x, int h, int w, int c, int wp,
                                                      const float* __restrict__ amax, _Float16* __restrict__ out) {
@@ -332,21 +337,17 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     float* amax = (float*)workspace;
     _Float16* xp = (_Float16*)((char*)workspace + 256);
     _Float16* dp = xp + p16_elems(n, h, w, cin);
-    hipError_t e = mpg::zero_async(amax, 256, s);
-    if (e == hipSuccess) e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    // amax[0] / amax[1]: the callers' values where given (one small kernel: device-to-device copies are slower graph
+    // nodes than a launch), zero where the reductions below fill them in
+    hipLaunchKernelGGL(amax_init_kernel, dim3(1), dim3(64), 0, s, amax, x_amax, dy_amax);
+    hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
     auto am_grid = [](size_t n) { const size_t b = (n + BLK * 16 - 1) / (BLK * 16); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
-    if (x_amax != nullptr)       // e.g. a forward activation whose scale the caller fixes (no reduction pass over x)
-        e = hipMemcpyAsync(amax, x_amax, sizeof(float), hipMemcpyDeviceToDevice, s);
-    else
+    if (x_amax == nullptr)       // else: e.g. a forward activation whose scale the caller fixes (no reduction pass over x)
         hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
-    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: copy of x_amax");
-    if (dy_amax != nullptr)      // the caller already reduced max |dy| (it scales the data gradient with it too)
-        e = hipMemcpyAsync(amax + 1, dy_amax, sizeof(float), hipMemcpyDeviceToDevice, s);
-    else
+    if (dy_amax == nullptr)      // else: the caller already has max |dy| (it scales the data gradient with it too)
         hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nd)), dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
-    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: copy of dy_amax");
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cin + 63) / 64), dim3(256), 0, s, x, h, w, cin, wp,
                        amax, xp);
     hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cout + 63) / 64), dim3(256), 0, s, dy, h, w, cout, wp,

@@ -19,6 +19,8 @@ MPG_LANES=1 python tools/probe_8x.py 2 3 > $O/c4_probe_1lane.txt 2>&1
 python tools/probe_small.py > $O/small_layers.txt 2>&1
 python tools/probe_transpose.py > $O/hbm_kernels.md 2>&1
 python tools/probe_split.py > $O/split.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_wgrad_fetch -- python tools/roofline_probe_wgrad.py 4 > $O/pmc_wgrad_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wgrad_write -- python tools/roofline_probe_wgrad.py 4 > $O/pmc_wgrad_write.log 2>&1
 python bench_train.py > $O/bt_c3.json 2> $O/bt_c3.err || true
 python bench_train.py --tile 64 > $O/bt_c3_64.json 2> $O/bt_c3_64.err || true
 python bench_train.py --workload c5 > $O/bt_c5.json 2> $O/bt_c5.err || true
