@@ -252,15 +252,22 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, size_t total, int c
     y[idx] = mpg::apply_act(v, act, leak);
 }
 
-// running max |v| into *out (float bits of a non-negative value; order like unsigned ints): one wave reduction, and the
-// atomic only when the wave's maximum beats what is already there (after the first waves almost never)
-__device__ __forceinline__ void wave_absmax_to(float v, unsigned int* __restrict__ out) {
-    float m = fabsf(v);
+// max |v| of a block into *out (float bits of a non-negative value order like unsigned ints): wave shuffles, LDS across the
+// waves, ONE atomic per block.  The kernels that use it run grid-stride with a capped grid, so a tensor costs a few
+// thousand atomics (one per wave on a single address made bn_bwd_apply_kernel 9x slower: measured, round 2).
+constexpr unsigned AMAX_GRID = 2048;
+
+__device__ __forceinline__ void block_absmax_to(float m, unsigned int* __restrict__ out) {
+    __shared__ float wave_max[BLK / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0) {
-        const unsigned bits = __float_as_uint(m);
-        if (bits > *reinterpret_cast<volatile unsigned int*>(out)) atomicMax(out, bits);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float b = wave_max[0];
+#pragma unroll
+        for (int w = 1; w < BLK / 64; ++w) b = fmaxf(b, wave_max[w]);
+        atomicMax(out, __float_as_uint(b));
     }
 }
 
@@ -270,16 +277,16 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ gamma, const float* __restrict__ dgamma,
                                     const float* __restrict__ dbeta, float eps, float inv_n, float* __restrict__ dx,
                                     unsigned int* __restrict__ amax) {
-    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
-    float v = 0.f;
-    if (idx < total) {
+    float m = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * BLK) {
         const int ch = idx % c;
         const float is = rsqrtf(var[ch] + eps);
         const float xh = (x[idx] - mean[ch]) * is;
-        v = gamma[ch] * is * (dy[idx] - dbeta[ch] * inv_n - xh * dgamma[ch] * inv_n);
+        const float v = gamma[ch] * is * (dy[idx] - dbeta[ch] * inv_n - xh * dgamma[ch] * inv_n);
         dx[idx] = v;
+        m = fmaxf(m, fabsf(v));
     }
-    if (amax != nullptr) wave_absmax_to(v, amax);
+    if (amax != nullptr) block_absmax_to(m, amax);
 }
 
 // ---------------------------------------------------------------- elementwise backward
@@ -287,18 +294,18 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // 0.5(1+leak) at 0 as tf.abs has a zero gradient there, GAN.py:733-737; tanh: 1 - y^2)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int act,
                                float leak, float* __restrict__ dx, unsigned int* __restrict__ amax) {
-    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
-    float v = 0.f;
-    if (idx < n) {
+    float m = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * BLK) {
         const float o = y[idx];
         float d = 1.f;
         if (act == MPG_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
         else if (act == MPG_ACT_LRELU) d = o > 0.f ? 1.f : (o < 0.f ? leak : 0.5f * (1.f + leak));
         else if (act == MPG_ACT_TANH) d = 1.f - o * o;
-        v = dy[idx] * d;
+        const float v = dy[idx] * d;
         dx[idx] = v;
+        m = fmaxf(m, fabsf(v));
     }
-    if (amax != nullptr) wave_absmax_to(v, amax);
+    if (amax != nullptr) block_absmax_to(m, amax);
 }
 
 // y = x * r, r = rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)); `lanes` consecutive lanes per pixel
@@ -800,7 +807,9 @@ extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const floa
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
     launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
     const size_t total = npix * c;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, dy, x, total, c, batch_mean,
+    unsigned g = grid_for(total);
+    if (amax != nullptr && g > AMAX_GRID) g = AMAX_GRID;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g), dim3(BLK), 0, s, dy, x, total, c, batch_mean,
                        batch_var, gamma, dgamma, dbeta, eps, 1.f / (float)npix, dx, (unsigned int*)amax);
     MPG_LAUNCH_CHECK("bn_train_bwd");
 }
@@ -814,8 +823,9 @@ extern "C" int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y,
         if (e != hipSuccess) return mpg::hip_check(e, "mpg_act_bwd: zero");
     }
     if (n == 0) return MPG_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx,
-                       (unsigned int*)amax);
+    unsigned g = grid_for(n);
+    if (amax != nullptr && g > AMAX_GRID) g = AMAX_GRID;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(g), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx, (unsigned int*)amax);
     MPG_LAUNCH_CHECK("act_bwd_kernel");
 }
 
