@@ -386,6 +386,43 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ gr,
     p[idx] -= lr_t * mm / (sqrtf(vv) + eps);
 }
 
+// long contractions (the discriminator's flatten -> 1: k = 262144 at 256^2 tiles) with one block per row leave the chip
+// empty (16 blocks, 320 us): split K over blockIdx.z, partial sums by atomics into a zeroed y, bias + activation after
+__global__ __launch_bounds__(256) void fc_splitk_kernel(const float* __restrict__ x, const float* __restrict__ w, int k, int cout,
+                                                        int kchunk, float wscale, float* __restrict__ y) {
+    __shared__ float red[BLK];
+    const int row = blockIdx.x, o0 = blockIdx.y * 64, tid = threadIdx.x;
+    const int no = min(64, cout - o0);
+    const int k0 = blockIdx.z * kchunk, k1 = min(k, k0 + kchunk);
+    const float* xr = x + (size_t)row * k;
+    if (no == 1) {
+        float s = 0.f;
+        for (int i = k0 + tid; i < k1; i += BLK) s = fmaf(xr[i], w[(size_t)i * cout + o0], s);
+        red[tid] = s;
+        __syncthreads();
+        for (int st = BLK / 2; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) atomicAdd(y + (size_t)row * cout + o0, red[0] * wscale);
+        return;
+    }
+    const int o = tid % 64, kl = tid / 64;
+    float s = 0.f;
+    if (o < no)
+        for (int i = k0 + kl; i < k1; i += 4) s = fmaf(xr[i], w[(size_t)i * cout + o0 + o], s);
+    red[tid] = s;
+    __syncthreads();
+    if (kl == 0 && o < no)
+        atomicAdd(y + (size_t)row * cout + o0 + o, (red[o] + red[64 + o] + red[128 + o] + red[192 + o]) * wscale);
+}
+
+__global__ void fc_finish_kernel(float* __restrict__ y, const float* __restrict__ bias, size_t n, int cout, int act, float leak) {
+    const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (idx >= n) return;
+    y[idx] = mpg::apply_act(y[idx] + (bias ? bias[idx % cout] : 0.f), act, leak);
+}
+
 // fully connected layer: y[r][o] = act(wscale * sum_k x[r][k] * w[k][o] + b[o]); one block per (row, 64 outputs),
 // the K range is strided over the block and reduced through LDS
 __global__ __launch_bounds__(256) void fc_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -742,7 +779,23 @@ extern "C" int mpg_fc_forward(mpg_stream_t stream, const float* x, int rows, int
     MPG_REQUIRE(x && w && y, "mpg_fc_forward: null pointer");
     MPG_REQUIRE(rows >= 1 && k >= 1 && cout >= 1, "mpg_fc_forward: bad shape");
     MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_fc_forward: bad activation %d", act);
-    hipLaunchKernelGGL(fc_fwd_kernel, dim3(rows, (cout + 63) / 64), dim3(BLK), 0, (hipStream_t)stream, x, w, bias, k,
+    const int ogroups = (cout + 63) / 64;
+    if (k >= 16384 && (size_t)rows * ogroups < 512) {
+        int splits = (int)(1024 / ((size_t)rows * ogroups));
+        if (splits > k / 2048) splits = k / 2048;                       // at least 2048 terms per block
+        if (splits > 1) {
+            const int kchunk = ((k + splits - 1) / splits + 255) / 256 * 256;
+            splits = (k + kchunk - 1) / kchunk;
+            hipError_t e = mpg::zero_async(y, (size_t)rows * cout * sizeof(float), (hipStream_t)stream);
+            if (e != hipSuccess) return mpg::hip_check(e, "mpg_fc_forward: zero");
+            hipLaunchKernelGGL(fc_splitk_kernel, dim3(rows, ogroups, splits), dim3(BLK), 0, (hipStream_t)stream, x, w, k, cout,
+                               kchunk, wscale, y);
+            hipLaunchKernelGGL(fc_finish_kernel, dim3(grid_for((size_t)rows * cout)), dim3(BLK), 0, (hipStream_t)stream, y, bias,
+                               (size_t)rows * cout, cout, act, leak);
+            MPG_LAUNCH_CHECK("fc_splitk_kernel");
+        }
+    }
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(rows, ogroups), dim3(BLK), 0, (hipStream_t)stream, x, w, bias, k,
                        cout, wscale, act, leak, y);
     MPG_LAUNCH_CHECK("fc_fwd_kernel");
 }

@@ -518,3 +518,21 @@ def test_gan_advect_through_the_builder():
     assert np.abs(got_sl - A.advect(src, vel, flags, 0.5, 1)).max() < 2e-5
     bad = np.abs(got_mc - A.advect(src, vel, flags, 0.5, 2, 1.0, n)) > 2e-5
     assert bad.mean() < 2e-3
+
+
+@pytest.mark.parametrize("rows,k,cout", [(3, 100, 1), (16, 20000, 1), (4, 40000, 5), (2, 16384, 70), (16, 262144, 1)])
+def test_fc_forward_short_and_split_k(rows, k, cout):
+    """GAN.fully_connected_layer (GAN.py:438-456); long contractions are split over K (atomic partial sums)"""
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import train_ops
+    rng = np.random.default_rng(rows * 7 + cout)
+    x = rng.standard_normal((rows, k)).astype(np.float32)
+    w = rng.standard_normal((k, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ws = float(1.0 / math.sqrt(k))
+    for act in (None, "lrelu"):
+        y = train_ops.fc_forward(dev(x), dev(w), ws, dev(b), act).cpu().numpy()
+        ref = x.astype(np.float64) @ w.astype(np.float64) * ws + b
+        if act == "lrelu":
+            ref = np.where(ref > 0, ref, 0.2 * ref)
+        assert np.abs(y - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), np.abs(y - ref).max()
