@@ -208,9 +208,91 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
     }
 }
 
+// The same sums with four channels per thread (c % 4 == 0, 16-byte loads, four pixels in flight per thread): the scalar
+// kernel above moves 1.7 TB/s on a 128-channel tensor, one 4-byte load per dependent iteration.
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_sum4_kernel(const float* __restrict__ a, const float* __restrict__ x, size_t npix,
+                                                        int c, int lanes, const float* __restrict__ aux0,
+                                                        const float* __restrict__ aux1, float inv_n, float eps,
+                                                        float* __restrict__ out0, float* __restrict__ out1,
+                                                        size_t pix_per_block) {
+    __shared__ float4 red0[BLK];
+    __shared__ float4 red1[BLK];
+    const int tid = threadIdx.x;
+    const int ppi = BLK / lanes;                 // pixels per iteration
+    const int lane = tid % lanes, row = tid / lanes;
+    const int ch = (blockIdx.y * lanes + lane) * 4;
+    const size_t p_begin = (size_t)blockIdx.x * pix_per_block;
+    const size_t p_end = min(npix, p_begin + pix_per_block);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ch < c) {
+        float m[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (MODE == 1) m[j] = aux0[ch + j] * inv_n;
+            if (MODE == 2) { m[j] = aux0[ch + j]; is[j] = rsqrtf(aux1[ch + j] + eps); }
+            if (MODE == 3) m[j] = bn_shift(a, npix, c, ch + j);
+        }
+        auto take = [&](const float4 v4, const float4 x4) {
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (MODE == 0) s0[j] += v[j];
+                if (MODE == 1) { const float d = v[j] - m[j]; s0[j] = fmaf(d, d, s0[j]); }
+                if (MODE == 2) { s0[j] += v[j]; s1[j] = fmaf(v[j], (xv[j] - m[j]) * is[j], s1[j]); }
+                if (MODE == 3) { const float d = v[j] - m[j]; s0[j] += d; s1[j] = fmaf(d, d, s1[j]); }
+            }
+        };
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        size_t p = p_begin + row;
+        for (; p + 3 * (size_t)ppi < p_end; p += 4 * (size_t)ppi) {
+            float4 v[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = *reinterpret_cast<const float4*>(a + (p + (size_t)u * ppi) * c + ch);
+                xv[u] = MODE == 2 ? *reinterpret_cast<const float4*>(x + (p + (size_t)u * ppi) * c + ch) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(v[u], xv[u]);
+        }
+        for (; p < p_end; p += ppi)
+            take(*reinterpret_cast<const float4*>(a + p * c + ch),
+                 MODE == 2 ? *reinterpret_cast<const float4*>(x + p * c + ch) : z4);
+    }
+    red0[tid] = make_float4(s0[0], s0[1], s0[2], s0[3]);
+    red1[tid] = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    __syncthreads();
+    if (row == 0 && ch < c) {
+        float4 t0 = red0[tid], t1 = red1[tid];
+        for (int r = 1; r < ppi; ++r) {
+            const float4 u0 = red0[r * lanes + lane], u1 = red1[r * lanes + lane];
+            t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w;
+            t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
+        }
+        atomicAdd(out0 + ch, t0.x); atomicAdd(out0 + ch + 1, t0.y); atomicAdd(out0 + ch + 2, t0.z); atomicAdd(out0 + ch + 3, t0.w);
+        if (MODE == 2 || MODE == 3) {
+            atomicAdd(out1 + ch, t1.x); atomicAdd(out1 + ch + 1, t1.y); atomicAdd(out1 + ch + 2, t1.z); atomicAdd(out1 + ch + 3, t1.w);
+        }
+    }
+}
+
 template <int MODE>
 void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix, int c, const float* aux0,
                      const float* aux1, float inv_n, float eps, float* out0, float* out1) {
+    if (c >= 16 && (c % 4) == 0 && (((uintptr_t)a) & 15) == 0 && (x == nullptr || (((uintptr_t)x) & 15) == 0)) {
+        int lanes = 1;
+        while (lanes < c / 4 && lanes < BLK) lanes <<= 1;
+        const int cblocks = (c / 4 + lanes - 1) / lanes;
+        const int ppi = BLK / lanes;
+        size_t blocks = (npix + (size_t)ppi * 16 - 1) / ((size_t)ppi * 16);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        const size_t ppb = (npix + blocks - 1) / blocks;
+        blocks = (npix + ppb - 1) / ppb;
+        hipLaunchKernelGGL((chan_sum4_kernel<MODE>), dim3((unsigned)blocks, cblocks), dim3(BLK), 0, s, a, x, npix, c, lanes,
+                           aux0, aux1, inv_n, eps, out0, out1, ppb);
+        return;
+    }
     int lanes = 1;
     while (lanes < c && lanes < BLK) lanes <<= 1;
     const int cblocks = (c + lanes - 1) / lanes;
@@ -239,6 +321,24 @@ __global__ void bn_finalize_kernel(float* mean, float* var, int c, float inv_n, 
     var[i] = v;
     if (moving_mean) moving_mean[i] = decay * moving_mean[i] + (1.f - decay) * m;
     if (moving_var) moving_var[i] = decay * moving_var[i] + (1.f - decay) * v;
+}
+
+// four channels per thread (c % 4 == 0)
+__global__ void bn_apply4_kernel(const float* __restrict__ x, size_t total4, int c, const float* __restrict__ mean,
+                                 const float* __restrict__ var, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, int act, float leak, float* __restrict__ y) {
+    const size_t i4 = (size_t)blockIdx.x * BLK + threadIdx.x;
+    if (i4 >= total4) return;
+    const int ch = (int)((i4 * 4) % c);
+    const float4 v = reinterpret_cast<const float4*>(x)[i4];
+    const float4 m = *reinterpret_cast<const float4*>(mean + ch), vr = *reinterpret_cast<const float4*>(var + ch);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + ch), bt = *reinterpret_cast<const float4*>(beta + ch);
+    float4 o;
+    o.x = mpg::apply_act((v.x - m.x) * rsqrtf(vr.x + eps) * g.x + bt.x, act, leak);
+    o.y = mpg::apply_act((v.y - m.y) * rsqrtf(vr.y + eps) * g.y + bt.y, act, leak);
+    o.z = mpg::apply_act((v.z - m.z) * rsqrtf(vr.z + eps) * g.z + bt.z, act, leak);
+    o.w = mpg::apply_act((v.w - m.w) * rsqrtf(vr.w + eps) * g.w + bt.w, act, leak);
+    reinterpret_cast<float4*>(y)[i4] = o;
 }
 
 // y = act((x - mean) * rsqrt(var + eps) * gamma + beta)
@@ -837,8 +937,13 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
                        moving_mean, moving_var, decay, x, npix);
 #endif
     const size_t total = npix * c;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
-                       gamma, beta, eps, act, leak, y);
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)y | (uintptr_t)batch_mean | (uintptr_t)batch_var | (uintptr_t)gamma | (uintptr_t)beta;
+    if ((c % 4) == 0 && (al & 15) == 0)
+        hipLaunchKernelGGL(bn_apply4_kernel, dim3(grid_for(total / 4)), dim3(BLK), 0, s, x, total / 4, c, batch_mean, batch_var,
+                           gamma, beta, eps, act, leak, y);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
+                           gamma, beta, eps, act, leak, y);
     MPG_LAUNCH_CHECK("bn_train_fwd");
 }
 

@@ -63,6 +63,28 @@ def test_conv2d_fused_single(gpu_ops, case, prec, tol):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("shape,c_off,cin", [((2, 9, 13, 128), 0, 128), ((1, 7, 33, 200), 8, 150), ((3, 5, 5, 36), 4, 32),
+                                             ((2, 6, 10, 260), 0, 260), ((1, 4, 40, 64), 32, 32)])
+@pytest.mark.parametrize("flavour", ["f16", "f8c"])
+def test_to_g8_wide_tensors_match_the_reference_layout(gpu_ops, shape, c_off, cin, flavour):
+    """wide tensors take the tiled conversion kernel (32 pixels x 128 channels per block): same bytes as the definition
+    -- hi = fp16(v), lo = fp16(v - hi) per channel, [N][group][plane][H][W][8], zeros beyond cin -- incl. channel windows,
+    ragged pixel counts, a channel count that is not a multiple of the tile, and the power-of-two scaling by max |x|"""
+    rng = _rng(sum(shape) + cin)
+    x = (rng.standard_normal(shape) * 3e-5).astype(np.float32)
+    fl = gpu_ops.G8_F16 if flavour == "f16" else gpu_ops.G8_F8C
+    for scaled in (False, True):
+        amax = gpu_ops.absmax(_t(x)) if scaled else None
+        g = gpu_ops.to_g8(_t(x), c_off, cin, fl, amax=amax)
+        # the narrow path (cin < 32) is the per-pixel kernel: converting 8-channel windows one by one is the reference
+        n, h, w, _ = shape
+        buf = g.buf.cpu().numpy()
+        for g0 in range(0, cin, 8):
+            k = min(8, cin - g0)
+            one = gpu_ops.to_g8(_t(x), c_off + g0, k, fl, amax=amax).buf.cpu().numpy()
+            assert np.array_equal(buf[:, g0 // 8].view(np.uint16), one[:, 0].view(np.uint16)), (g0, scaled)
+
+
 def test_g8_roundtrip_and_chained_convs(gpu_ops):
     """fp32 <-> G8 conversion (hi + lo fp16 planes) and two convolutions chained through a G8
     tensor, the way the session passes activations between fused launches"""
