@@ -245,15 +245,16 @@ __global__ __launch_bounds__(256) void chan_sum4_kernel(const float* __restrict_
         };
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         size_t p = p_begin + row;
-        for (; p + 3 * (size_t)ppi < p_end; p += 4 * (size_t)ppi) {
-            float4 v[4], xv[4];
+        constexpr int UN = MODE == 2 ? 4 : 8;      // pixels in flight per thread
+        for (; p + (UN - 1) * (size_t)ppi < p_end; p += UN * (size_t)ppi) {
+            float4 v[UN], xv[UN];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 v[u] = *reinterpret_cast<const float4*>(a + (p + (size_t)u * ppi) * c + ch);
                 xv[u] = MODE == 2 ? *reinterpret_cast<const float4*>(x + (p + (size_t)u * ppi) * c + ch) : z4;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) take(v[u], xv[u]);
+            for (int u = 0; u < UN; ++u) take(v[u], xv[u]);
         }
         for (; p < p_end; p += ppi)
             take(*reinterpret_cast<const float4*>(a + p * c + ch),
@@ -284,8 +285,9 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
         while (lanes < c / 4 && lanes < BLK) lanes <<= 1;
         const int cblocks = (c / 4 + lanes - 1) / lanes;
         const int ppi = BLK / lanes;
+        // every block ends in one atomic per channel: 2048 blocks queued ~100 us of atomics on each address
         size_t blocks = (npix + (size_t)ppi * 16 - 1) / ((size_t)ppi * 16);
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 512) blocks = 512;
         if (blocks < 1) blocks = 1;
         const size_t ppb = (npix + blocks - 1) / blocks;
         blocks = (npix + ppb - 1) / ppb;
@@ -331,8 +333,11 @@ __global__ void bn_apply4_kernel(const float* __restrict__ x, size_t total4, int
     if (i4 >= total4) return;
     const int ch = (int)((i4 * 4) % c);
     const float4 v = reinterpret_cast<const float4*>(x)[i4];
-    const float4 m = *reinterpret_cast<const float4*>(mean + ch), vr = *reinterpret_cast<const float4*>(var + ch);
-    const float4 g = *reinterpret_cast<const float4*>(gamma + ch), bt = *reinterpret_cast<const float4*>(beta + ch);
+    // the per-channel vectors may be views into a flat parameter buffer: no alignment assumed
+    const float4 m = make_float4(mean[ch], mean[ch + 1], mean[ch + 2], mean[ch + 3]);
+    const float4 vr = make_float4(var[ch], var[ch + 1], var[ch + 2], var[ch + 3]);
+    const float4 g = make_float4(gamma[ch], gamma[ch + 1], gamma[ch + 2], gamma[ch + 3]);
+    const float4 bt = make_float4(beta[ch], beta[ch + 1], beta[ch + 2], beta[ch + 3]);
     float4 o;
     o.x = mpg::apply_act((v.x - m.x) * rsqrtf(vr.x + eps) * g.x + bt.x, act, leak);
     o.y = mpg::apply_act((v.y - m.y) * rsqrtf(vr.y + eps) * g.y + bt.y, act, leak);
@@ -395,16 +400,23 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, int act,
                                float leak, float* __restrict__ dx, unsigned int* __restrict__ amax) {
     float m = 0.f;
-    for (size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * BLK) {
-        const float o = y[idx];
+    auto one = [&](float g, float o) {
         float d = 1.f;
         if (act == MPG_ACT_RELU) d = o > 0.f ? 1.f : 0.f;
         else if (act == MPG_ACT_LRELU) d = o > 0.f ? 1.f : (o < 0.f ? leak : 0.5f * (1.f + leak));
         else if (act == MPG_ACT_TANH) d = 1.f - o * o;
-        const float v = dy[idx] * d;
-        dx[idx] = v;
+        const float v = g * d;
         m = fmaxf(m, fabsf(v));
+        return v;
+    };
+    const bool vec = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dx)) & 15) == 0;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n4; i += (size_t)gridDim.x * BLK) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i], o = reinterpret_cast<const float4*>(y)[i];
+        reinterpret_cast<float4*>(dx)[i] = make_float4(one(g.x, o.x), one(g.y, o.y), one(g.z, o.z), one(g.w, o.w));
     }
+    for (size_t idx = n4 * 4 + (size_t)blockIdx.x * BLK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * BLK)
+        dx[idx] = one(dy[idx], y[idx]);
     if (amax != nullptr) block_absmax_to(m, amax);
 }
 
@@ -937,7 +949,7 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
                        moving_mean, moving_var, decay, x, npix);
 #endif
     const size_t total = npix * c;
-    const uintptr_t al = (uintptr_t)x | (uintptr_t)y | (uintptr_t)batch_mean | (uintptr_t)batch_var | (uintptr_t)gamma | (uintptr_t)beta;
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)y;
     if ((c % 4) == 0 && (al & 15) == 0)
         hipLaunchKernelGGL(bn_apply4_kernel, dim3(grid_for(total / 4)), dim3(BLK), 0, s, x, total / 4, c, batch_mean, batch_var,
                            gamma, beta, eps, act, leak, y);
@@ -981,8 +993,8 @@ extern "C" int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y,
         if (e != hipSuccess) return mpg::hip_check(e, "mpg_act_bwd: zero");
     }
     if (n == 0) return MPG_OK;
-    unsigned g = grid_for(n);
-    if (amax != nullptr && g > AMAX_GRID) g = AMAX_GRID;
+    unsigned g = grid_for((n + 3) / 4);
+    if (g > AMAX_GRID) g = AMAX_GRID;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(g), dim3(BLK), 0, (hipStream_t)stream, dy, y, n, act, leak, dx, (unsigned int*)amax);
     MPG_LAUNCH_CHECK("act_bwd_kernel");
 }
