@@ -325,25 +325,35 @@ __global__ void bn_finalize_kernel(float* mean, float* var, int c, float inv_n, 
     if (moving_var) moving_var[i] = decay * moving_var[i] + (1.f - decay) * v;
 }
 
-// four channels per thread (c % 4 == 0)
-__global__ void bn_apply4_kernel(const float* __restrict__ x, size_t total4, int c, const float* __restrict__ mean,
-                                 const float* __restrict__ var, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, int act, float leak, float* __restrict__ y) {
-    const size_t i4 = (size_t)blockIdx.x * BLK + threadIdx.x;
-    if (i4 >= total4) return;
-    const int ch = (int)((i4 * 4) % c);
-    const float4 v = reinterpret_cast<const float4*>(x)[i4];
-    // the per-channel vectors may be views into a flat parameter buffer: no alignment assumed
-    const float4 m = make_float4(mean[ch], mean[ch + 1], mean[ch + 2], mean[ch + 3]);
-    const float4 vr = make_float4(var[ch], var[ch + 1], var[ch + 2], var[ch + 3]);
-    const float4 g = make_float4(gamma[ch], gamma[ch + 1], gamma[ch + 2], gamma[ch + 3]);
-    const float4 bt = make_float4(beta[ch], beta[ch + 1], beta[ch + 2], beta[ch + 3]);
-    float4 o;
-    o.x = mpg::apply_act((v.x - m.x) * rsqrtf(vr.x + eps) * g.x + bt.x, act, leak);
-    o.y = mpg::apply_act((v.y - m.y) * rsqrtf(vr.y + eps) * g.y + bt.y, act, leak);
-    o.z = mpg::apply_act((v.z - m.z) * rsqrtf(vr.z + eps) * g.z + bt.z, act, leak);
-    o.w = mpg::apply_act((v.w - m.w) * rsqrtf(vr.w + eps) * g.w + bt.w, act, leak);
-    reinterpret_cast<float4*>(y)[i4] = o;
+// four channels per thread (c % 4 == 0, c <= 512): the per-channel vectors (possibly unaligned views into a flat parameter
+// buffer) are staged in LDS once per block -- 16 scalar parameter loads per thread made this kernel slower than the
+// one-element version -- and every thread streams 16 bytes of x per step of a grid-stride loop
+constexpr int BN4_CMAX = 512;
+
+__global__ __launch_bounds__(256) void bn_apply4_kernel(const float* __restrict__ x, size_t total4, int c,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        int act, float leak, float* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float par[4][BN4_CMAX];
+    for (int i = threadIdx.x; i < c; i += BLK) {
+        par[0][i] = mean[i];
+        par[1][i] = rsqrtf(var[i] + eps);
+        par[2][i] = gamma[i];
+        par[3][i] = beta[i];
+    }
+    __syncthreads();
+    for (size_t i4 = (size_t)blockIdx.x * BLK + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * BLK) {
+        const int ch = (int)((i4 * 4) % (size_t)c);
+        const float4 v = reinterpret_cast<const float4*>(x)[i4];
+        const float4 m = *reinterpret_cast<const float4*>(&par[0][ch]), is = *reinterpret_cast<const float4*>(&par[1][ch]);
+        const float4 g = *reinterpret_cast<const float4*>(&par[2][ch]), bt = *reinterpret_cast<const float4*>(&par[3][ch]);
+        float4 o;
+        o.x = mpg::apply_act((v.x - m.x) * is.x * g.x + bt.x, act, leak);
+        o.y = mpg::apply_act((v.y - m.y) * is.y * g.y + bt.y, act, leak);
+        o.z = mpg::apply_act((v.z - m.z) * is.z * g.z + bt.z, act, leak);
+        o.w = mpg::apply_act((v.w - m.w) * is.w * g.w + bt.w, act, leak);
+        reinterpret_cast<float4*>(y)[i4] = o;
+    }
 }
 
 // y = act((x - mean) * rsqrt(var + eps) * gamma + beta)
@@ -950,9 +960,12 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
 #endif
     const size_t total = npix * c;
     const uintptr_t al = (uintptr_t)x | (uintptr_t)y;
-    if ((c % 4) == 0 && (al & 15) == 0)
-        hipLaunchKernelGGL(bn_apply4_kernel, dim3(grid_for(total / 4)), dim3(BLK), 0, s, x, total / 4, c, batch_mean, batch_var,
+    if ((c % 4) == 0 && c <= BN4_CMAX && (al & 15) == 0) {
+        unsigned g = grid_for(total / 4);
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(bn_apply4_kernel, dim3(g), dim3(BLK), 0, s, x, total / 4, c, batch_mean, batch_var,
                            gamma, beta, eps, act, leak, y);
+    }
     else
         hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(BLK), 0, s, x, total, c, batch_mean, batch_var,
                            gamma, beta, eps, act, leak, y);
