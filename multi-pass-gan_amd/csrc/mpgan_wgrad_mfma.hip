@@ -237,11 +237,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 #pragma unroll
                 for (int t = 0; t < COTW; ++t)
                     bfr[pln][t] = *reinterpret_cast<const half8*>(db + pln * dch * a.drowb + t * 32 * a.drowb + j * 32);
+            // the shifted A fragments of all taps first, then the products in product-major order: consecutive MFMAs go
+            // to different accumulators (three back-to-back products into one accumulator wait for each other with one
+            // wave per SIMD)
+            half8 afr[KW][2];
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
                 // pixels [8 + s, 16 + s) of the window, s = kx - pl (|s| <= 3)
                 const int s = kx - (KW - 1) / 2;
-                half8 afr[2];
 #pragma unroll
                 for (int pln = 0; pln < nplane; ++pln) {
                     u32x4 f;
@@ -254,16 +257,25 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
                         for (int i = 0; i < 4; ++i)
                             f[i] = __builtin_amdgcn_alignbit(win[pln][q + i + 1], win[pln][q + i], 16);
                     }
-                    afr[pln] = __builtin_bit_cast(half8, f);
+                    afr[kx][pln] = __builtin_bit_cast(half8, f);
                 }
+            }
 #pragma unroll
-                for (int t = 0; t < COTW; ++t) {
-                    acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfr[0][t], acc[kx][t], 0, 0, 0);
-                    if (PREC == 3) {
-                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[0], bfr[1][t], acc[kx][t], 0, 0, 0);
-                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[1], bfr[0][t], acc[kx][t], 0, 0, 0);
-                    }
-                }
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int t = 0; t < COTW; ++t)
+                    acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][0], bfr[0][t], acc[kx][t], 0, 0, 0);
+            if (PREC == 3) {
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                    for (int t = 0; t < COTW; ++t)
+                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][0], bfr[1][t], acc[kx][t], 0, 0, 0);
+#pragma unroll
+                for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                    for (int t = 0; t < COTW; ++t)
+                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][1], bfr[0][t], acc[kx][t], 0, 0, 0);
             }
         }
         if (wi + 1 < nwork) stash(buf ^ 1);
