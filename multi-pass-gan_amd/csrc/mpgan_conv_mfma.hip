@@ -1588,6 +1588,10 @@ const char* zero_buffer() {
 
 }  // namespace
 
+namespace mpg {
+const char* zero_page() { return zero_buffer(); }
+}  // namespace mpg
+
 extern "C" size_t mpg_g8_bytes(int n, int h, int w, int c) {
     if (n < 1 || h < 1 || w < 1 || c < 1) return 0;
     return (size_t)n * ((c + 7) / 8) * 2 * h * w * 16;

@@ -34,6 +34,10 @@ inline int hip_check(hipError_t e, const char* what) {
 // kernel node does not.
 hipError_t zero_async(void* ptr, size_t bytes, hipStream_t stream);
 
+// 256 zero bytes of device memory (per device, allocated on first use outside any capture): the source of LDS-DMA lanes
+// that must deliver zeros.  nullptr when the allocation failed.
+const char* zero_page();
+
 __device__ __forceinline__ float apply_act(float v, int act, float leak) {
     // MPG_ACT_RELU: tf.nn.relu; MPG_ACT_LRELU: 0.5(1+leak) x + 0.5(1-leak)|x| (GAN.py:733-737)
     if (act == MPG_ACT_RELU) return fmaxf(v, 0.f);

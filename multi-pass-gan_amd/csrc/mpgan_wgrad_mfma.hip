@@ -87,10 +87,19 @@ __global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x
     }
 }
 
+#ifndef MPG_WG_DIAG
+#define MPG_WG_DIAG 0
+#endif
+#if MPG_WG_DIAG
+__device__ unsigned long long g_wg_diag[8];
+#define WG_T() __builtin_readcyclecounter()
+#endif
+
 struct WgArgs {
     const _Float16* xp;      // P16 of x  [N][H][cin_total][2][wp]
     const _Float16* dp;      // P16 of dy [N][H][cout_total][2][wp]
     const float* amax;       // [0] x, [1] dy
+    const char* zeros;       // >= 16 zero bytes: the source of padding / out-of-row units of the LDS-DMA copy
     float* dw;               // [kh][kw][cin_total][cout_total]
     int n, h, w, wp;
     int cin_total, cout_total, ci0, co0, cin, cout;   // channel window of this launch (cin, cout <= 128)
@@ -106,6 +115,9 @@ struct WgArgs {
 // prefetch registers for the x piece: 10 units (a 64-pixel chunk of 128 channels, hi + lo) where the
 // accumulators leave room, else 6 (32-pixel chunks)
 constexpr int x_units(int kw, int cotw) { return kw * cotw > 12 ? 6 : 10; }
+// with the pad unit that ends every LDS row (bank spread), per thread
+constexpr int x_units_dma(int kw, int cotw) { return x_units(kw, cotw) + 2; }
+constexpr int D_UNITS_DMA = 5;
 
 template <int KW, int COTW, int PREC>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
@@ -132,12 +144,12 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
     char* xs[2] = {lds, lds + xbytes + dbytes};
     char* dsm[2] = {lds + xbytes, lds + 2 * xbytes + dbytes};
 
-    // global -> LDS copy plan: 16-byte units; unit -> (row = channel*nplane + plane, offset)
-    const int xupr = (a.chunk + 16) / 8, dupr = a.chunk / 8;          // units per row
+    // global -> LDS copy: LDS-DMA, 16 bytes per lane, every wave instruction fills 1 KiB of the image linearly.  The image
+    // is [plane][channel][units of 8 pixels + one pad unit] (the pad spreads the rows over the banks; it is never
+    // written or read), so unit u = (plane * channels + channel) * units_per_row + offset lands at byte 16 u.
+    const int xupr = (a.chunk + 16) / 8 + 1, dupr = a.chunk / 8 + 1;  // units per row incl. the pad unit
     const int xunits = xch * nplane * xupr, dunits = dch * nplane * dupr;
-    constexpr int XU = x_units(KW, COTW), DU = 4;                      // 16-byte units per thread and chunk
-    u32x4 xreg[XU], dreg[DU];
-
+    constexpr int XU = x_units_dma(KW, COTW), DU = D_UNITS_DMA;        // DMA instructions per wave and chunk
     const int total_rows = a.n * a.h;
     const int row_begin = split * a.rows_per_split;
     const int row_end = min(total_rows, row_begin + a.rows_per_split);
@@ -152,71 +164,99 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[k][t][v] = 0.f;
 
-    auto fetch = [&](int wi) {
+    // copy plan of this thread, formed once: per unit its offset inside a P16 row block (halves) and its pixel offset
+    // inside the chunk.  (A first version staged the chunk through registers: 10 global loads + 10 ds_write_b128 per thread
+    // and chunk took 2100 + 1700 cycles next to 3840 cycles of MFMA work, with nothing to hide them behind at one wave
+    // per SIMD -- measured with MPG_WG_DIAG; the wide LDS stores alone run at a third of the read rate.)
+    constexpr int NOPX = 1 << 28;                 // pixel offset of a unit that delivers zeros whatever the chunk
+    constexpr int SKIP = -(1 << 28);              // ... of a unit that is not copied at all (pad unit, beyond the image)
+    int xg[XU], xpo[XU], dg[DU], dpo[DU];
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+        const int u = tid + i * 256;
+        const int rr = u / xupr, off = u % xupr;
+        const int pln = rr / xch, ch = rr % xch;
+        xg[i] = ((a.ci0 + ch) * 2 + pln) * a.wp + off * 8 - 8;
+        xpo[i] = (u >= xunits || off == xupr - 1) ? SKIP : (ch < a.cin ? off * 8 - 8 : NOPX);
+    }
+#pragma unroll
+    for (int i = 0; i < DU; ++i) {
+        const int u = tid + i * 256;
+        const int rr = u / dupr, off = u % dupr;
+        const int pln = rr / dch, ch = rr % dch;
+        dg[i] = ((co_base + ch) * 2 + pln) * a.wp + off * 8;
+        dpo[i] = (u >= dunits || off == dupr - 1) ? SKIP : (ch < a.cout ? off * 8 : NOPX);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // (the copy of a chunk is written in NPART parts so that variants can place them; the CU's address unit takes ~40 cycles
+    // per LDS-DMA instruction of this shape: 3000 cycles for the 68 instructions of a chunk, measured)
+    constexpr int NPART = 4;
+    struct ChunkAt { const _Float16* xrow; const _Float16* drow; int x0; bool row_ok; };
+    auto chunk_at = [&](int wi) {
         const int row = row_begin + wi / chunks_per_row;        // output row b*h + oy
         const int x0 = (wi % chunks_per_row) * a.chunk;
         const int oy = row % a.h;
         const int iy = oy + ky - a.pt;
-        const bool row_ok = iy >= 0 && iy < a.h;
-        const size_t xrow = (size_t)(row - oy + iy) * a.cin_total;
-        const size_t drow = (size_t)row * a.cout_total;
-#pragma unroll
-        for (int i = 0; i < XU; ++i) {
-            const int u = tid + i * 256;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (u < xunits && row_ok) {
-                const int rr = u / xupr, off = u % xupr;
-                const int ch = rr / nplane, pln = rr % nplane;
-                const int px = x0 - 8 + off * 8;
-                if (ch < a.cin && px >= 0 && px < a.wp)
-                    v = *reinterpret_cast<const u32x4*>(a.xp + ((xrow + a.ci0 + ch) * 2 + pln) * a.wp + px);
-            }
-            xreg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < DU; ++i) {
-            const int u = tid + i * 256;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (u < dunits && row_ok) {
-                const int rr = u / dupr, off = u % dupr;
-                const int ch = rr / nplane, pln = rr % nplane;
-                const int px = x0 + off * 8;
-                if (ch < a.cout && px < a.wp)
-                    v = *reinterpret_cast<const u32x4*>(a.dp + ((drow + co_base + ch) * 2 + pln) * a.wp + px);
-            }
-            dreg[i] = v;
-        }
+        ChunkAt c;
+        c.x0 = x0;
+        c.row_ok = iy >= 0 && iy < a.h;
+        c.xrow = a.xp + (size_t)(row - oy + iy) * a.cin_total * 2 * a.wp + x0;
+        c.drow = a.dp + (size_t)row * a.cout_total * 2 * a.wp + x0;
+        return c;
     };
-    auto stash = [&](int buf) {
+    auto dma_part = [&](const ChunkAt& c, int buf, auto part_c) {
+        constexpr int P = decltype(part_c)::value;
+        const int x0 = c.x0;
+        const bool row_ok = c.row_ok;
+        const _Float16* xrow = c.xrow;
+        const _Float16* drow = c.drow;
 #pragma unroll
-        for (int i = 0; i < XU; ++i) {
-            const int u = tid + i * 256;
-            if (u < xunits) {
-                const int rr = u / xupr, off = u % xupr;
-                const int ch = rr / nplane, pln = rr % nplane;
-                *reinterpret_cast<u32x4*>(xs[buf] + (pln * xch + ch) * a.xrowb + off * 16) = xreg[i];
+        for (int i = P; i < XU; i += NPART) {
+            if (xpo[i] != SKIP) {
+                const int px = x0 + xpo[i];
+                const char* src = (row_ok && px >= 0 && px < a.wp) ? reinterpret_cast<const char*>(xrow + xg[i]) : a.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs[buf] + (i * 4 + wave_u) * 1024),
+                                                 16, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < DU; ++i) {
-            const int u = tid + i * 256;
-            if (u < dunits) {
-                const int rr = u / dupr, off = u % dupr;
-                const int ch = rr / nplane, pln = rr % nplane;
-                *reinterpret_cast<u32x4*>(dsm[buf] + (pln * dch + ch) * a.drowb + off * 16) = dreg[i];
+        for (int i = P; i < DU; i += NPART) {
+            if (dpo[i] != SKIP) {
+                const char* src = (row_ok && x0 + dpo[i] < a.wp) ? reinterpret_cast<const char*>(drow + dg[i]) : a.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dsm[buf] + (i * 4 + wave_u) * 1024),
+                                                 16, 0, 0);
             }
         }
     };
 
-    if (nwork > 0) {
-        fetch(0);
-        stash(0);
-    }
+    auto dma_parts_from = [&](const ChunkAt& c, int buf, int first) {      // parts first .. NPART-1 (first is wave-uniform)
+        if (first <= 0) dma_part(c, buf, std::integral_constant<int, 0>{});
+        if (first <= 1) dma_part(c, buf, std::integral_constant<int, 1>{});
+        if (first <= 2) dma_part(c, buf, std::integral_constant<int, 2>{});
+        if (first <= 3) dma_part(c, buf, std::integral_constant<int, 3>{});
+    };
+    if (nwork > 0) dma_parts_from(chunk_at(0), 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int ksteps = a.chunk / 16;
+#if MPG_WG_DIAG
+    unsigned long long d_fetch = 0, d_comp = 0, d_stash = 0, d_bar = 0, d_wait = 0;
+    const unsigned long long t_begin = WG_T();
+#endif
     for (int wi = 0; wi < nwork; ++wi) {
         const int buf = wi & 1;
-        if (wi + 1 < nwork) fetch(wi + 1);
+#if MPG_WG_DIAG
+        const unsigned long long t0 = WG_T();
+#endif
+        // the whole next chunk at once: spreading the LDS-DMA instructions between the MFMA phases was measured SLOWER
+        // (9900 against 9000 cycles per chunk): with one wave per SIMD every instruction stalls the wave while the CU's
+        // address unit works, and the matrix pipe drains each time
+        if (wi + 1 < nwork) dma_parts_from(chunk_at(wi + 1), buf ^ 1, 0);
+#if MPG_WG_DIAG
+        const unsigned long long t1 = WG_T();
+#endif
         const char* xb = xs[buf] + (cit * 32 + r) * a.xrowb + hh * 16;
         const char* db = dsm[buf] + ((cog * COTW) * 32 + r) * a.drowb + hh * 16;
         for (int j = ks; j < ksteps && ks < a.ks; j += a.ks) {
@@ -278,9 +318,25 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
                         acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][1], bfr[0][t], acc[kx][t], 0, 0, 0);
             }
         }
-        if (wi + 1 < nwork) stash(buf ^ 1);
+#if MPG_WG_DIAG
+        const unsigned long long t2a = WG_T();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = WG_T();
+        d_wait += t2 - t2a;
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next chunk has landed in the other buffer
+#if MPG_WG_DIAG
+        const unsigned long long t3 = WG_T();
+#endif
         __syncthreads();
+#if MPG_WG_DIAG
+        const unsigned long long t4 = WG_T();
+        d_fetch += t1 - t0; d_comp += t2a - t1; d_stash += t3 - t2; d_bar += t4 - t3;
+#endif
     }
+#if MPG_WG_DIAG
+    const unsigned long long t_loop = WG_T();
+#endif
 
     // epilogue: D row = (v&3) + 8*(v>>2) + 4*(lane>>5) is the input channel, column lane&31 the output channel
     const float unscale = a.wscale / (pow2_scale(a.amax[0]) * pow2_scale(a.amax[1]));
@@ -299,6 +355,14 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
                               val * unscale);
             }
         }
+#if MPG_WG_DIAG
+    if (lane == 0 && blockIdx.x % 64 == 0) {
+        const unsigned long long t_end = WG_T();
+        atomicAdd(&g_wg_diag[0], d_fetch); atomicAdd(&g_wg_diag[1], d_comp); atomicAdd(&g_wg_diag[2], d_stash);
+        atomicAdd(&g_wg_diag[3], d_bar); atomicAdd(&g_wg_diag[4], t_loop - t_begin); atomicAdd(&g_wg_diag[5], d_wait);
+        atomicAdd(&g_wg_diag[6], 1ull); atomicAdd(&g_wg_diag[7], (unsigned long long)nwork);
+    }
+#endif
 }
 
 template <int KW, int COTW, int PREC>
@@ -314,6 +378,14 @@ hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes, 
 inline size_t p16_elems(int n, int h, int w, int c) { return (size_t)n * h * c * 2 * ((w + 7) & ~7); }
 
 }  // namespace
+
+#if MPG_WG_DIAG
+extern "C" int mpg_debug_wg_diag(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wg_diag), 64) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wg_diag), z, 64) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 
 extern "C" int mpg_absmax(mpg_stream_t stream, const float* x, size_t n, float* out) {
     MPG_REQUIRE(x && out, "mpg_absmax: null pointer");
@@ -345,6 +417,8 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
                     (((uintptr_t)workspace) & 255) == 0,
                 "mpg_conv2d_wgrad_mfma: workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
+    const char* zeros = mpg::zero_page();
+    MPG_REQUIRE(zeros != nullptr, "mpg_conv2d_wgrad_mfma: could not allocate the zero page");
     const int wp = (w + 7) & ~7;
     float* amax = (float*)workspace;
     _Float16* xp = (_Float16*)((char*)workspace + 256);
@@ -372,7 +446,7 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
     for (int ci0 = 0; ci0 < cin; ci0 += 128)
         for (int co0 = 0; co0 < (merged ? 1 : cout); co0 += co_step) {
             WgArgs a;
-            a.xp = xp; a.dp = dp; a.amax = amax; a.dw = dw;
+            a.xp = xp; a.dp = dp; a.amax = amax; a.dw = dw; a.zeros = zeros;
             a.n = n; a.h = h; a.w = w; a.wp = wp;
             a.cin_total = cin; a.cout_total = cout; a.ci0 = ci0; a.co0 = co0;
             a.cin = cin - ci0 < 128 ? cin - ci0 : 128;
@@ -390,17 +464,18 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
             const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
             a.ks = 4 / (a.cit * a.cog);                           // waves left over split the 16-pixel k-steps of a chunk
             a.chunk = 32 * a.ks < 64 ? 64 : 32 * a.ks;            // fewer barriers per pixel with 64-pixel chunks
-            const int xu = x_units(kw, cotw);
-            // short rows, and at most xu / 4 16-byte units per thread in the copy plan
-            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8) > xu * 256 ||
-                                    a.cog * cotw * 32 * npl * (a.chunk / 8) > 4 * 256))
+            const int xu = x_units_dma(kw, cotw);
+            // short rows, and at most xu (x) / D_UNITS_DMA (dy) LDS-DMA instructions per wave in the copy plan
+            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8 + 1) > xu * 256 ||
+                                    a.cog * cotw * 32 * npl * (a.chunk / 8 + 1) > D_UNITS_DMA * 256))
                 a.chunk /= 2;
             if (a.chunk / 16 < a.ks) a.ks = a.chunk / 16;         // the other waves idle (tiny layers)
             a.xrowb = (a.chunk + 16) * 2 + 16;
             a.drowb = a.chunk * 2 + 16;
             const size_t lds = 2 * ((size_t)a.cit * 32 * npl * a.xrowb + (size_t)a.cog * cotw * 32 * npl * a.drowb);
             MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_wgrad_mfma: LDS plan %zu bytes", lds);
-            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8) <= xu * 256 && a.cog * cotw * 32 * npl * (a.chunk / 8) <= 4 * 256,
+            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8 + 1) <= xu * 256 &&
+                            a.cog * cotw * 32 * npl * (a.chunk / 8 + 1) <= D_UNITS_DMA * 256,
                         "mpg_conv2d_wgrad_mfma: copy plan");
             const int rows = n * h;
             int want = 1024 / kh;
