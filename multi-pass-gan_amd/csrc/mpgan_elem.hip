@@ -355,27 +355,34 @@ struct TileArgs {
 // instead of one: half as many separate DRAM bursts per byte as the 32 x 32 tile it replaces, which averaged 3.3 TB/s
 // on the 256^3 permutations, profiles/r01), rows padded to 65 words (conflict-free column reads).  Tiles are walked in
 // an XCD-interleaved order so that the blocks resident at one time spread over the strided axis.
+#ifndef MPG_TR_TILE
+#define MPG_TR_TILE 64
+#endif
+constexpr int TRT = MPG_TR_TILE;           // tile edge: 64 (256-byte rows both ways) or 128 (512-byte rows, 66 KB of LDS)
+
 __global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __restrict__ v, TileArgs a, float* __restrict__ out) {
-    __shared__ float tile[64][65];
+    extern __shared__ float tile_lds[];
+    float (*tile)[TRT + 1] = reinterpret_cast<float (*)[TRT + 1]>(tile_lds);
     int bid = blockIdx.x;
     const int tb = bid % a.tiles_b; bid /= a.tiles_b;
     const int ta = bid % a.tiles_a;
     const int rr = bid / a.tiles_a;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
-    const int a0 = ta * 64, b0 = tb * 64;
+    constexpr int RP = 256 / TRT;                              // tile rows per pass of the 256 threads
+    const int tx = threadIdx.x % TRT, ty = threadIdx.x / TRT;
+    const int a0 = ta * TRT, b0 = tb * TRT;
     const float* src = v + (size_t)rr * a.sin_r;
 #pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int ia = a0 + ty + 4 * k, ib = b0 + tx;
-        if (ia < a.da && ib < a.db) tile[ty + 4 * k][tx] = __builtin_nontemporal_load(src + (size_t)ia * a.sin_a + ib);
+    for (int k = 0; k < TRT / RP; ++k) {
+        const int ia = a0 + ty + RP * k, ib = b0 + tx;
+        if (ia < a.da && ib < a.db) tile[ty + RP * k][tx] = __builtin_nontemporal_load(src + (size_t)ia * a.sin_a + ib);
     }
     __syncthreads();
     float* dst = out + (size_t)rr * a.sout_r;
 #pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int ib = b0 + ty + 4 * k, ia = a0 + tx;
+    for (int k = 0; k < TRT / RP; ++k) {
+        const int ib = b0 + ty + RP * k, ia = a0 + tx;
         if (ia < a.da && ib < a.db) {
-            float val = tile[tx][ty + 4 * k];
+            float val = tile[tx][ty + RP * k];
             if (a.cutoff > 0.f && val < a.cutoff) val = 0.f;
             __builtin_nontemporal_store(val, dst + (size_t)ib * a.sout_b + ia);
         }
@@ -658,11 +665,17 @@ extern "C" int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0,
         t.da = a.din[ax_a]; t.db = d2; t.dr = a.din[ax_r];
         t.sin_a = sin[ax_a]; t.sin_r = sin[ax_r];
         t.sout_b = sout_of_in[2]; t.sout_r = sout_of_in[ax_r];
-        t.tiles_a = (t.da + 63) / 64; t.tiles_b = (t.db + 63) / 64;
+        t.tiles_a = (t.da + TRT - 1) / TRT; t.tiles_b = (t.db + TRT - 1) / TRT;
         t.cutoff = cutoff;
         const size_t nblk = (size_t)t.tiles_a * t.tiles_b * t.dr;
         MPG_REQUIRE(nblk < (1UL << 31), "mpg_volume_transpose: grid too large");
-        hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)nblk), dim3(BLK), 0, (hipStream_t)stream, v, t, out);
+        constexpr size_t tile_bytes = (size_t)TRT * (TRT + 1) * sizeof(float);
+        if (tile_bytes > 48 * 1024) {
+            static int lds_limit[64] = {0};
+            hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&transpose_tiled_kernel), (int)tile_bytes, lds_limit);
+            if (e != hipSuccess) return mpg::hip_check(e, "mpg_volume_transpose: dynamic LDS");
+        }
+        hipLaunchKernelGGL(transpose_tiled_kernel, dim3((unsigned)nblk), dim3(BLK), tile_bytes, (hipStream_t)stream, v, t, out);
         MPG_LAUNCH_CHECK("transpose_tiled_kernel");
     }
     if (c == 1 && ident_map && perm[0] == 1 && perm[1] == 0 && perm[2] == 2 && d2 % 4 == 0 && ((uintptr_t)v & 15) == 0 &&
