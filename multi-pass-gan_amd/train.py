@@ -1200,7 +1200,7 @@ class Trainer8x(object):
         return ops.resize_nearest(ys.reshape(-1, cur, cur, 1).contiguous(), th, th).reshape(-1, th * th)
 
     # ------------------------------------------------------------------ temporal branch
-    def _frames_as_channels(self, frames, y_pos, xts=None, percentage=3.0):
+    def _frames_as_channels(self, frames, y_pos, xts=None, cur_size=None):
         """advection look-up at the CURRENT stage's resolution (the positions come at tileSizeLow * 2^stage):
         generated frames are nearest-downsampled to it, resampled, and resized back (:1178-1200)"""
         th = self.cfg.tileSizeHigh
@@ -1209,7 +1209,7 @@ class Trainer8x(object):
         if self.adv_flag:
             if self.adv_mode:
                 tl = self.cfg.tileSizeLow
-                pc = tl * 2 ** int(math.ceil(percentage)) if self.cfg.upsampling_mode == 2 else th   # currentTileSizeX
+                pc = cur_size                                # currentTileSizeX (:1180-1184): the fed targets' resolution
                 pos = None
             else:
                 pos = torch.as_tensor(y_pos, dtype=torch.float32, device=frames.device)
@@ -1240,8 +1240,10 @@ class Trainer8x(object):
         else:       # rows of (target, previous pass) pairs: the real frames are channel 0 (:1218-1219)
             gen_ts = self.sess.run([self.gen_ts], {self.x_t: xts, self.y_t2: yts, self.percentage: percentage})[0]
             yts = yts.reshape(-1, self.cfg.n_output, 2)[:, :, 0].contiguous()
-        fake = self._frames_as_channels(gen_ts, batch_y_pos, xts, percentage)
-        real = self._frames_as_channels(yts, batch_y_pos, xts, percentage)
+        # resolution of the current growing stage = that of the fed targets (tileSizeLow * 2^ceil(percentage), :1180-1181)
+        cur_size = int(round(math.sqrt(yts.reshape(yts.shape[0], -1).shape[1]))) if self.cfg.upsampling_mode == 2 else self.cfg.tileSizeHigh
+        fake = self._frames_as_channels(gen_ts, batch_y_pos, xts, cur_size)
+        real = self._frames_as_channels(yts, batch_y_pos, xts, cur_size)
         gen_s, disc_s = self.sess.run([self.gen_s, self.disc_s], {self.t_fake: fake, self.t_real: real,
                                                                    self.percentage: percentage})
         L = {"t_loss_y": self._adv(disc_s, True), "t_loss_g": self._adv(gen_s, False)}

@@ -203,13 +203,20 @@ def test_4x_training_driver(tmp_path, lambda_t):
             "frame_min", 0, "frame_max", 6, "genModel", "gen_resnet", "discModel", "disc_binclass", "randSeed", 42,
             "batchSize", 4, "trainingEpochs", 3, "outputInterval", 1, "saveInterval", 2, "lambda", 5.0, "lambda_t", lambda_t,
             "data_fraction", 1.0, "dataAugmentation", 0, "upsamplingMode", 2, "upsampledData", 0, "adam_beta1", 0.5,
-            "learningRate", 0.0002, "batchNorm", 1]
+            "learningRate", 0.0002, "batchNorm", 1, "decayLR", 1, "lambda_f", 0.99, "lambda2_f", 0.98, "keepMax", 2]
     out = _run("multipassGAN-4x.py", args, str(tmp_path))
     assert "TRAINING FINISHED" in out and "Epoch 00003/3" in out
     test_dir = tmp_path / "models" / "test_0000"
     assert (test_dir / "params.json").exists()
     p0 = checkpoint.load(str(test_dir / "model_0000.ckpt"))
     p1 = checkpoint.load(str(test_dir / "model_0001.ckpt"))
+    # the Saver's optimiser slots travel with the variables (and a resumed run restores them)
+    assert p1["generator/g_cB1/weight/Adam"].shape == (5, 5, 128, 128) and int(p1["gen/adam_t"]) == 3
+    out2 = _run("multipassGAN-4x.py", args[:] + ["load_model_test", 0, "load_model_no", 1, "trainingEpochs", 1, "keepMax", 1],
+                str(tmp_path))
+    assert "variables with optimiser slots" in out2 and "(0 variables with optimiser slots)" not in out2
+    p2 = checkpoint.load(str(tmp_path / "models" / "test_0001" / "model_0000.ckpt"))
+    assert int(p2["gen/adam_t"]) == 4
     assert "generator/g_cB1/weight" in p1 and p1["generator/g_cB1/weight"].shape == (5, 5, 128, 128)
     assert ("discriminatorTempo/t_c1/weight" in p1) == (lambda_t > 0)
     assert not np.array_equal(p0["generator/g_cB1/weight"], p1["generator/g_cB1/weight"])
@@ -224,7 +231,8 @@ def test_4x_training_driver(tmp_path, lambda_t):
     assert v.shape == (64, 64, 64, 1) and np.isfinite(v).all()
 
 
-def test_8x_training_driver(tmp_path):
+@pytest.mark.parametrize("adv_mode", [0, 2])
+def test_8x_training_driver(tmp_path, adv_mode):
     """example_run_training.py's first command (reduced sizes): three growing stages with their own targets,
     WGAN-GP spatial + temporal critics, checkpoints + moving-average checkpoints under the TF names, and the
     trained generator runs in multipassGAN-out.py"""
@@ -248,12 +256,13 @@ def test_8x_training_driver(tmp_path):
             "dropout", 0.5, "dataDim", 2, "batchSize", 3, "useVelocities", 1, "useVorticities", 0, "useK_Eps_Turb", 0,
             "useFlags", 0, "gif", 0, "genModel", "gen_resnet", "discModel", "disc_binclass",
             "basePath", str(tmp_path / "models") + "/", "packedSimPath", str(tmp_path / "data") + "/", "lambda_t", 1.0,
-            "lambda_t_l2", 0.0, "frame_max", 2, "frame_min", 0, "data_fraction", 1.0, "adv_flag", 1, "adv_mode", 0,
+            "lambda_t_l2", 0.0, "frame_max", 2, "frame_min", 0, "data_fraction", 1.0, "adv_flag", 1, "adv_mode", adv_mode,
             "dataAugmentation", 0, "premadeTiles", 0, "rot", 1, "minScale", 0.85, "maxScale", 1.15, "flip", 1, "decayLR", 1,
             "adam_beta1", 0.0, "adam_beta2", 0.99, "learningRate", 0.0001, "lossScaling", 1, "stageIter", 2, "decayIter", 2,
             "maxFms", 32, "startFms", 32, "filterSize", 3, "upsamplingMode", 2, "upsampledData", 0, "load_model_test", -1,
-            "load_model_no", -1, "firstNNArch", 1, "add_adj_idcs", 1, "usePixelShuffle", 0, "addBicubicUpsample", 1,
+            "load_model_no", -1, "firstNNArch", 1, "add_adj_idcs", 0 if adv_mode else 1, "usePixelShuffle", 0, "addBicubicUpsample", 1,
             "startingIter", 0, "useVelInTDisc", 0, "upsampleMode", 1, "gpu", 0, "saveInterval", 100]
+    # (adv_mode 1 / 2 slice the velocity out of a 4-channel x_t, 8x.py:1187: not together with the two add_adj channels)
     out = _run("multipassGAN-8x.py", args, str(tmp_path))
     assert "TRAINING FINISHED" in out and "NEW UPRES: 4" in out and "NEW UPRES: 8" in out
     assert "blending percentage: 3.000000" in out
@@ -272,7 +281,7 @@ def test_8x_training_driver(tmp_path):
              "genModel", "gen_resnet", "discModel", "disc_binclass", "basePath", str(tmp_path / "models") + "/",
              "packedSimPath", str(tmp_path / "data") + "/", "frame_max", 1, "frame_min", 0, "velScale", 1.0, "genUni", 1,
              "upsampleMode", 1, "usePixelShuffle", 0, "loadEmas", 0, "addBicubicUpsample", 1, "gpu", 0, "transposeAxis", 0,
-             "firstNNArch", 1, "load_model_test_1", 0, "load_model_no_1", 2, "use_res_net1", 1, "add_adj_idcs1", 1,
+             "firstNNArch", 1, "load_model_test_1", 0, "load_model_no_1", 2, "use_res_net1", 1, "add_adj_idcs1", 0 if adv_mode else 1,
              "startFms1", 32, "maxFms1", 32, "filterSize1", 3, "load_model_test_2", -1, "load_model_no_2", -1,
              "use_res_net2", 1, "add_adj_idcs2", 0, "startFms2", 192, "maxFms2", 192, "filterSize2", 5,
              "load_model_test_3", -1, "load_model_no_3", -1, "use_res_net3", 0, "add_adj_idcs3", 0, "startFms3", 192,
