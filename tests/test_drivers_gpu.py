@@ -274,6 +274,15 @@ def test_8x_training_driver(tmp_path, adv_mode):
     assert wname in last and all(np.isfinite(v).all() for v in last.values())
     assert not np.array_equal(first[wname], last[wname]) and not np.array_equal(ema[wname], last[wname])
     assert "tempo-disc/tBlock8/t_cA8/weight" in last and "spatial-disc/d_l61/weight" in last
+    # per-stage optimiser slots and loss-scale state travel with the variables; a resumed run restores them
+    assert "generator/genBlock8/g_cA_first/weight/Adam_4" in last and "gen/stage2/ls_var" in last
+    if adv_mode == 0:
+        ri = args.index("load_model_test")
+        rargs = list(args)
+        rargs[ri + 1] = 0
+        rargs[rargs.index("load_model_no") + 1] = 2
+        out_r = _run("multipassGAN-8x.py", rargs, str(tmp_path))
+        assert "optimiser slot pairs" in out_r and "(0 optimiser slot pairs)" not in out_r and "TRAINING FINISHED" in out_r
     # the trained first network in output mode
     (tmp_path / "models" / "test_0004").mkdir()
     oargs = ["randSeed", 200, "upRes", 8, "pixelNorm", 1, "batchNorm", 0, "out", 1, "tileSize", sim, "simSize", sim,
