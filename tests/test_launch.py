@@ -55,6 +55,7 @@ def test_bench_parent_launches_children_without_touching_the_gpu():
                        env=env, capture_output=True, text=True, timeout=500)
     assert p.returncode != 0
     # the sharded job fails, the parent then tries the exchange-free partition (whole volumes per rank), which fails too
-    assert p.stderr.count("needs an MI355X") == 4, p.stderr[-2000:]
+    # (a rank may be stopped by the launcher before it has printed, once its sibling has failed: 2..4 messages)
+    assert 2 <= p.stderr.count("needs an MI355X") <= 4, p.stderr[-2000:]
     assert "measuring whole volumes per rank instead" in p.stderr
     assert "{" not in p.stdout
