@@ -301,10 +301,25 @@ def main(argv=None):
         return dt, outs
 
     sharded_first = args.mode in ("both", "sharded") or world == 1
-    dt, outs = timed(g1, g2, replicas=not sharded_first)
+    extra = {}
+    if world > 1 and sharded_first:
+        # the sharded pipeline is the only part that needs RCCL.  If it raises on any rank (agreed on over the gloo control
+        # group), every rank measures the exchange-free partition instead and the line says so -- the same fallback the
+        # self-launching parent applies when a whole job dies, for runs started under torch.distributed.run
+        err = None
+        try:
+            dt, outs = timed(g1, g2, replicas=False)
+        except Exception as e:                       # noqa: BLE001 -- anything RCCL / the runtime throws
+            err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
+            sys.stderr.write("bench.py rank %d: the sharded run failed (%s); measuring whole volumes per rank instead\n" % (rank, err))
+        if comm.max_float(1.0 if err else 0.0, device) > 0:
+            args.mode, sharded_first = "replicas", False
+            extra["sharded_error"] = err or "another rank failed"
+            dt, outs = timed(g1, g2, replicas=True)
+    else:
+        dt, outs = timed(g1, g2, replicas=not sharded_first)
     checksum = float(outs[0].double().sum().item())
     del outs
-    extra = {}
     if world > 1 and args.mode == "both":
         dt_r, o = timed(g1, g2, replicas=True)
         del o
