@@ -225,7 +225,13 @@ class GAN(object):
 
     # GAN.py:624-631
     def noise(self, channels=-1):
-        raise NotImplementedError("noise layers are not used by the multi-pass generators")
+        # as many noise channels as the layer has, or `channels` of them, N(0, 0.04), appended on the channel axis
+        nch = int(channels) if channels > 0 else int(self.layer.get_shape()[-1])
+        self.layer_num += 1
+        noise = G.random_normal_like(self.layer, nch, 0.04, seed=self.layer_num)
+        self.layer = G.concat([self.layer, noise], axis=-1)
+        _say("Noise {}: {}".format(noise.get_shape(), self.layer.get_shape()))
+        return self.layer
 
     # GAN.py:635-638
     def concat(self, layer):

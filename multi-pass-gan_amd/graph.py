@@ -155,6 +155,14 @@ def concat(values, axis=-1):
     return Node("concat", values, shape=shape)
 
 
+def random_normal_like(x, channels, stddev, seed=0):
+    """tf.random_normal(shape of x with `channels` channels, mean 0, stddev) (GAN.noise, GAN.py:624-631): fresh values
+    every run; `seed` selects the stream (the reference draws from TensorFlow's global generator)"""
+    shape = list(x.shape)
+    shape[-1] = int(channels)
+    return Node("random_normal", [x], shape=shape, stddev=float(stddev), seed=int(seed))
+
+
 def slice_channels(x, begin, size):
     """tf.slice(x, [0,0,0,begin], [-1,h,w,size]) (multipassGAN-out.py:330)."""
     shape = list(x.shape)

@@ -546,6 +546,18 @@ class Session(object):
         if op == "avg_pool":
             x = n.inputs[0]
             return [x], lambda env: ops.avg_pool2(self._f32(env, x))
+        if op == "random_normal":
+            x = n.inputs[0]
+
+            def run_noise(env, n=n, x=x):
+                ref = self._f32(env, x)
+                gen = self.__dict__.setdefault("_noise_gen", {})
+                if n.id not in gen:
+                    gen[n.id] = torch.Generator(device=ref.device).manual_seed(1000003 * n.attrs["seed"] + 17)
+                shape = tuple(ref.shape[:-1]) + (n.shape[-1],)
+                return torch.randn(shape, generator=gen[n.id], device=ref.device, dtype=torch.float32) * n.attrs["stddev"]
+
+            return [x], run_noise
         if op == "max_pool":
             x = n.inputs[0]
             return [x], lambda env: ops.max_pool(self._f32(env, x), n.attrs["k"], n.attrs["s"])

@@ -588,6 +588,13 @@ class TrainSession(object):
             x = None if n.attrs["zero_x"] else ev(n.inputs[0])
             y = ev(n.inputs[-1])
             return (Lerp2Fn if self._higher(n) else LerpFn).apply(x, y, t)
+        if op == "random_normal":
+            ref = ev(n.inputs[0])
+            gen = self.__dict__.setdefault("_noise_gen", {})
+            if n.id not in gen:
+                gen[n.id] = torch.Generator(device=ref.device).manual_seed(1000003 * n.attrs["seed"] + 17)
+            shape = tuple(ref.shape[:-1]) + (n.shape[-1],)
+            return torch.randn(shape, generator=gen[n.id], device=ref.device, dtype=torch.float32) * n.attrs["stddev"]
         if op == "max_pool":
             if self._higher(n):
                 raise NotImplementedError("second-order gradient through max_pool (no reference network uses it)")

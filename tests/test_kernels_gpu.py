@@ -581,3 +581,27 @@ def test_depth_to_space_and_deconv_layer(gpu_ops, mpg):
         w2 = params["g_cPS1/weight"]
         r2 = O.depth_to_space(O.bias_add(O.conv2d_same(r, w2 * O.wscale(w2.shape)), params["g_cPS1/bias"]), 2)
         assert got_ps.shape == (2, 24, 24, 8) and rel_l2(got_ps, r2) < 2 * tol
+
+
+def test_gan_noise_layer(mpg):
+    """GAN.noise (GAN.py:624-631): N(0, 0.04) channels appended; new values every run"""
+    from mpgan_amd import graph as G
+    from mpgan_amd.GAN import GAN
+    from mpgan_amd.session import Session, VariableStore
+    prev = G.get_default_graph()
+    g = G.reset_default_graph()
+    try:
+        xin = G.placeholder([None, 32, 32, 3])
+        out = GAN(xin).noise()
+        out5 = GAN(xin).noise(channels=5)
+    finally:
+        G._default_graph[0] = prev
+    assert tuple(out.shape[1:]) == (32, 32, 6) and tuple(out5.shape[1:]) == (32, 32, 8)
+    sess = Session(graph=g, variables=VariableStore(DEV), device=DEV)
+    x = _rng(1).standard_normal((4, 32, 32, 3)).astype(np.float32)
+    a, b5 = sess.run([out, out5], {xin: x})
+    a2 = sess.run([out], {xin: x})[0]
+    assert np.array_equal(a[..., :3], x) and np.array_equal(b5[..., :3], x)
+    nz = a[..., 3:]
+    assert abs(float(nz.mean())) < 2e-3 and abs(float(nz.std()) - 0.04) < 2e-3
+    assert not np.array_equal(a2[..., 3:], nz)
