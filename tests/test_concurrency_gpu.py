@@ -46,10 +46,11 @@ def test_single_launches_next_to_mfma_launches_of_other_streams(mpg):
                 assert torch.equal(o, ref[i]), "launch %d differs under concurrency (rep %d)" % (i, rep)
 
 
-def test_generator_calls_on_four_streams(mpg):
+@pytest.mark.parametrize("prec", [2, 3])
+def test_generator_calls_on_four_streams(mpg, prec):
     from mpgan_amd import multipass as MP
     cfg = dict(tile_low=64, up_res=4, channels=1, upsampling_mode=1, batch_norm=True)
-    g = MP.Generator("gen_resnet", cfg, None, 2, device=DEV, seed=778)
+    g = MP.Generator("gen_resnet", cfg, None, prec, device=DEV, seed=778)
     gens = [g] + [g.clone() for _ in range(3)]
     xs = [torch.rand((8, 256, 256, 1), device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) for i in range(4)]
     ref = []
