@@ -8,7 +8,7 @@ Differences, all deliberate: weights come from ``model_%04d.ckpt.npz`` (see chec
 ``synthWeights 1`` (extra, optional) falls back to seeded random weights when a checkpoint is
 missing; PNG previews are skipped (scipy.misc.imsave no longer exists); three loaded networks
 run as three passes (the reference exits on an inverted check, :624-626); ``prec`` selects the
-arithmetic (2 = MPG_PREC_F16F8, default; 3 = MPG_PREC_F16X3).  ``transposeAxis`` 0..3 pick the slicing
+arithmetic (2 = MPG_PREC_F16F6, default; 3 = MPG_PREC_F16X3).  ``transposeAxis`` 0..3 pick the slicing
 axes of the passes exactly as :397-547 do, including what is broken there: the third pass of
 transposeAxis 2 raises the reference's IndexError (:542); ``add_adj_idcs2/3`` are ignored (the
 reference's code for them writes past the array it allocates, :488-500).
@@ -55,7 +55,7 @@ firstNNArch = int(ph.getParam("firstNNArch", True))
 transposeAxis = int(ph.getParam("transposeAxis", 0))
 gpu = ph.getParam("gpu", "0")
 synthWeights = int(ph.getParam("synthWeights", 0))          # extension: seeded random weights if no checkpoint
-prec = ph.getParam("prec", "2")                             # extension: 2 = f16f8 (default), 3 = f16x3 (fp32-grade)
+prec = ph.getParam("prec", "2")                             # extension: 2 = f16f6 (default), 3 = f16x3 (fp32-grade)
 nets = []
 for k in (1, 2, 3):
     nets.append(dict(

@@ -35,8 +35,9 @@ SLICES_PER_VOLUME = 2 * S
 GFLOP_PER_SLICE = 71.692
 DENSE_F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PARITY_TOL = 1e-3                        # BASELINE.json north_star: relative L2 on density fields
-PREC_NAME = {3: "f16x3", 2: "f16f8", 1: "f16x1"}
-ROUND = "r02"
+PREC_NAME = {3: "f16x3", 2: "f16f6", 1: "f16x1"}
+DTYPE_NAME = {3: "f16x3->f32", 2: "f16+2xbf6->f32", 1: "f16->f32"}
+ROUND = "r03"
 
 
 def parse_args(argv=None):
@@ -46,13 +47,12 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--volumes-per-gpu", type=int, default=8)
     ap.add_argument("--prec", type=int, default=2, choices=(1, 2, 3),
-                    help="arithmetic of `value`: 2 = MPG_PREC_F16F8 (product default), 3 = MPG_PREC_F16X3, "
+                    help="arithmetic of `value`: 2 = MPG_PREC_F16F6 (product default), 3 = MPG_PREC_F16X3, "
                          "1 = MPG_PREC_F16X1 (outside the 1e-3 tolerance)")
     ap.add_argument("--slice-batch", type=int, default=8, help="slices per generator launch (reference: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the oracle parity it carries)")
     ap.add_argument("--no-second-prec", action="store_true", help="skip the second timed figure (value_f16x3)")
     ap.add_argument("--cpu-slices", type=int, default=12, help="slices per pass of the CPU leg (>= 8)")
-    ap.add_argument("--sharded-error", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--lanes", type=int, default=2,
                     help="HIP streams the independent volumes are dealt to (multipass.two_pass_4x_batch lanes)")
     ap.add_argument("--mode", default="both", choices=("both", "sharded", "replicas"),
@@ -71,19 +71,28 @@ def gen_resnet_flops_per_slice(c=1, hw=256 * 256):
 
 
 def launch_self(args, argv):
-    """parent of an N-rank run: no GPU call in this process"""
+    """parent of an N-rank run: no GPU call in this process.  A failed sharded run (the north_star configuration: slice-axis
+    sharding + RCCL all-gather) is a FAILED benchmark: the exchange-free partition is still measured, by a fresh job, but
+    only as `value_replicas` next to `value: null`, and the exit code is non-zero."""
     from mpgan_amd import launch
     rc, out = launch.spawn_ranks(os.path.abspath(__file__), argv, args.gpus, timeout=args.launch_timeout)
     line = launch.last_json_line(out)
     if (rc != 0 or line is None) and args.mode != "replicas":
-        # the sharded path needs RCCL (all-gather between the passes); if that job dies, still measure the partition
-        # that needs no exchange -- whole volumes per rank, control traffic over gloo -- and say so in the line
         sys.stderr.write(out)
-        sys.stderr.write("bench.py: the sharded run failed (rc %s); measuring whole volumes per rank instead\n" % rc)
-        rc, out = launch.spawn_ranks(os.path.abspath(__file__), list(argv) + ["--mode", "replicas", "--sharded-error",
-                                                                             "rc %s" % rc],
-                                     args.gpus, timeout=args.launch_timeout)
-        line = launch.last_json_line(out)
+        sys.stderr.write("bench.py: the sharded run failed (rc %s); measuring whole volumes per rank for the record\n" % rc)
+        rc2, out2 = launch.spawn_ranks(os.path.abspath(__file__), list(argv) + ["--mode", "replicas", "--no-cpu-baseline",
+                                                                               "--no-second-prec"],
+                                       args.gpus, timeout=args.launch_timeout)
+        line2 = launch.last_json_line(out2)
+        res = failed_line(args, "sharded run: rc %s" % rc)
+        if rc2 == 0 and line2 is not None:
+            rep = json.loads(line2)
+            res["value_replicas"] = rep.get("value")
+            res["ms_per_step_replicas"] = rep.get("ms_per_step")
+            res["config"] = rep.get("config", res["config"])
+        print(json.dumps(res))
+        sys.stdout.flush()
+        return rc or 1
     if line is not None:
         print(line)
     else:
@@ -91,6 +100,17 @@ def launch_self(args, argv):
         rc = rc or 1
     sys.stdout.flush()
     return rc
+
+
+def failed_line(args, err):
+    """the JSON line of a run whose sharded pipeline failed: no `value`"""
+    return {"metric": "volumes/sec (4x two-pass generator inference, 64^3->256^3 density-only)", "value": None,
+            "unit": "volumes/s", "n_gpus": args.gpus, "rccl_ranks": 0, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.prec], "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 4x two-pass gen_resnet inference, 64^3->256^3 density-only, "
+                                   "%d volumes per GPU resident in HBM" % args.volumes_per_gpu},
+            "sharded_error": err}
 
 
 def _time_events(fn, iters, device, torch):
@@ -147,8 +167,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
     segs = [ops.Segment(a, pkb), ops.Segment(x, pks)]     # inputs converted to the G8 layout once, outside the loop
 
     def launch():
-        return ops.conv2d_fused(segs, (h, w), bias=bias, act="relu", want_f32=False, want_g8=(prec != 2),
-                                want_g8c=(prec == 2))
+        return ops.conv2d_fused(segs, (h, w), bias=bias, act="relu", want_f32=False, want_g8=True)
 
     for _ in range(3):
         launch()
@@ -158,7 +177,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
     # HBM bytes per launch of this very launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     # per MI355X_MICROARCH.md + WRITE_SIZE); null for other modes
     traffic = src = None
-    for rnd in (ROUND, "r01"):
+    for rnd in (ROUND, "r02", "r01"):
         pmc = os.path.join(ROOT, "profiles", rnd, "roofline_pmc_b1convB.json")
         if prec == 2 and os.path.exists(pmc):
             with open(pmc) as f:
@@ -167,7 +186,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
             break
     return {
         "bound": "mfma",
-        "kernel": "conv_mfma%s_kernel<NT=4> prec %d (resBlock1 convB 5x5 128->128 + 1x1 8->128 shortcut, 8 slices of 256^2)" % ("_f8" if prec == 2 else "", prec),
+        "kernel": "conv_mfma%s_kernel<NT=4> prec %d (resBlock1 convB 5x5 128->128 + 1x1 8->128 shortcut, 8 slices of 256^2)" % ("_f6" if prec == 2 else "", prec),
         "achieved": round(achieved, 2),
         "peak": DENSE_F16_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -181,7 +200,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
         "launch_ms_replay": round(ms_pipe, 4) if ms_pipe is not None else None,
         "launch_ms_random": round(ms_rand, 4),
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
-        "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 fp8 (MX, K=64)", 1: "1 fp16"}[prec],
+        "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 bf6 (MX e3m2, K=64 in the cycles of one fp16 K=16): 1.5 fp16-equivalent units", 1: "1 fp16"}[prec],
     }
 
 
@@ -303,19 +322,19 @@ def main(argv=None):
     sharded_first = args.mode in ("both", "sharded") or world == 1
     extra = {}
     if world > 1 and sharded_first:
-        # the sharded pipeline is the only part that needs RCCL.  If it raises on any rank (agreed on over the gloo control
-        # group), every rank measures the exchange-free partition instead and the line says so -- the same fallback the
-        # self-launching parent applies when a whole job dies, for runs started under torch.distributed.run
-        err = None
+        # the sharded pipeline is the only part that needs RCCL.  A rank on which it raises does not go on computing on a
+        # runtime that has just thrown: it reports and exits non-zero (the launcher -- launch.spawn_ranks or
+        # torch.distributed.run -- then ends the other ranks); a self-launched job is followed by a fresh replicas job
         try:
             dt, outs = timed(g1, g2, replicas=False)
         except Exception as e:                       # noqa: BLE001 -- anything RCCL / the runtime throws
             err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
-            sys.stderr.write("bench.py rank %d: the sharded run failed (%s); measuring whole volumes per rank instead\n" % (rank, err))
-        if comm.max_float(1.0 if err else 0.0, device) > 0:
-            args.mode, sharded_first = "replicas", False
-            extra["sharded_error"] = err or "another rank failed"
-            dt, outs = timed(g1, g2, replicas=True)
+            sys.stderr.write("bench.py rank %d: the sharded run failed (%s)\n" % (rank, err))
+            if rank == 0:
+                print(json.dumps(failed_line(args, err)))
+                sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)
     else:
         dt, outs = timed(g1, g2, replicas=not sharded_first)
     checksum = float(outs[0].double().sum().item())
@@ -338,8 +357,6 @@ def main(argv=None):
     if rank != 0:
         return 0
     vol_per_s = n_vol * args.steps / dt
-    if args.sharded_error:
-        extra["sharded_error"] = args.sharded_error
     replicas_only = world > 1 and args.mode == "replicas"
     result = {
         "metric": "volumes/sec (4x two-pass generator inference, 64^3->256^3 density-only)",
@@ -353,7 +370,7 @@ def main(argv=None):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {3: "f16x3->f32", 2: "f16+2xfp8->f32", 1: "f16->f32"}[args.prec],
+        "dtype": DTYPE_NAME[args.prec],
         "data": "synthetic",
         "config": {
             "workload": "BASELINE configs[1]: 4x two-pass gen_resnet inference, 64^3->256^3 density-only, "
@@ -366,7 +383,7 @@ def main(argv=None):
                             "slice-axis sharding x%d + all-gather between passes, exchanges overlapped with the next volume" % world)
                            if world > 1 else "single GPU",
             "precision": {3: "MPG_PREC_F16X3 (fp16 hi/lo split, three fp16 MFMA products, fp32 accumulate)",
-                          2: "MPG_PREC_F16F8 (fp16 product + two fp8 MX correction products, fp32 accumulate; the "
+                          2: "MPG_PREC_F16F6 (fp16 product + two bf6 MX block-scaled correction products, fp32 accumulate; the "
                              "default of the inference drivers, `prec` parameter)",
                           1: "MPG_PREC_F16X1 (outside the 1e-3 tolerance)"}[args.prec],
         },

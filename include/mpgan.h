@@ -37,14 +37,15 @@ enum { MPG_ACT_NONE = 0, MPG_ACT_RELU = 1, MPG_ACT_LRELU = 2, MPG_ACT_TANH = 3 }
  * F16X1: one fp16 term per operand (fast, ~3e-4 relative error per layer);
  * F16X3: hi/lo fp16 split of both operands, three MFMA products
  *        (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo), fp32-equivalent (~1e-6). */
-enum { MPG_PREC_F16X1 = 1, MPG_PREC_F16F8 = 2, MPG_PREC_F16X3 = 3 };
-/* F16F8: the fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and a_hi*w_lo
- *        on the block-scaled fp8 (e4m3) MFMA path at twice the fp16 rate per K: ~2^-15 per
- *        operand, 2/3 of the F16X3 matrix work. */
+enum { MPG_PREC_F16X1 = 1, MPG_PREC_F16F6 = 2, MPG_PREC_F16X3 = 3 };
+/* F16F6: the fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and a_hi*w_lo
+ *        on the block-scaled bf6 (e3m2) MFMA path at four times the fp16 rate per K, with true MX
+ *        block scales (per lane and 32 K values, formed in registers from the fp16 fragments):
+ *        ~2^-14 per operand at any input range, half of the F16X3 matrix work. */
 
-/* flavours of a G8 tensor's second plane: fp16 lo (F16X3 / F16X1 launches) or the packed
- * {8 x fp8 hi | 8 x fp8 lo} bytes the F16F8 launches read */
-enum { MPG_G8_F16 = 0, MPG_G8_F8C = 1 };
+/* flavour of a G8 tensor's second plane: fp16 lo (every launch reads it since round 3; the
+ * {8 x fp8 hi | 8 x fp8 lo} flavour of rounds 1-2 is gone) */
+enum { MPG_G8_F16 = 0 };
 
 const char* mpg_last_error(void);
 /* library / device probe: returns MPG_OK when a gfx950 device is usable. */
@@ -91,7 +92,7 @@ typedef struct mpg_conv_seg {
     int32_t g_off;       /* first group consumed */
     int32_t kh, kw;      /* kernel size, 1..7 */
     int32_t up_log2;     /* fused nearest upsample: src = (y >> up_log2, x >> up_log2) */
-    int32_t w_exp;       /* F16F8 only: the exponent the weights were packed with */
+    int32_t reserved0;   /* must be 0 */
     int32_t pad_hi;           /* 0: TF SAME, pad_before = (k-1)/2; 1: pad_before = k/2 (the data gradient of an even filter) */
 } mpg_conv_seg;
 
@@ -109,8 +110,7 @@ typedef struct mpg_conv_desc {
     int32_t post_add_stride;
     int32_t post_add_coff;
     float*  y;                /* fp32 NHWC [N,H,W,cout] or NULL */
-    void*   y_g8;             /* G8 (MPG_G8_F16) with ceil(cout/8) groups or NULL */
-    void*   y_g8c;            /* G8 (MPG_G8_F8C) or NULL; at least one of the three outputs */
+    void*   y_g8;             /* G8 (MPG_G8_F16) with ceil(cout/8) groups or NULL; at least one of the two outputs */
     int32_t prec;             /* MPG_PREC_* */
     int32_t reserved;         /* must be 0 */
     const float* in_amax;     /* NULL, or device pointer to the absolute maximum the segment inputs were scaled by
@@ -119,7 +119,7 @@ typedef struct mpg_conv_desc {
 } mpg_conv_desc;
 
 /* bytes of the packed weight image of one segment; 0 when the shape is not available at `prec` (kernel larger
- * than 7x7, cout > 128, or -- MPG_PREC_F16F8 only -- LDS images that do not fit, e.g. 7x7 with cout > 96:
+ * than 7x7, cout > 128, or -- MPG_PREC_F16F6 only -- LDS images that do not fit, e.g. 7x7 with cout > 96:
  * pack such a segment for MPG_PREC_F16X3 instead). */
 size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec);
 
@@ -130,9 +130,7 @@ size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec);
 int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw,
                           int w_cin_total, int w_c_off, int cin, int cout,
                           float wscale, const float* cout_scale,
-                          int prec, int w_exp, void* out, size_t out_bytes);
-/* w_exp (F16F8 only): fp8 planes hold w * 2^w_exp and (w - fp16(w)) * 2^(w_exp+11); choose it
- * so that max|w| * 2^w_exp <= 448 (the e4m3 range), e.g. floor(log2(224 / max|w|)). */
+                          int prec, void* out, size_t out_bytes);
 
 int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* desc);
 

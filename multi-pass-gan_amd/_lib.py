@@ -14,8 +14,8 @@ if os.environ.get("MPGAN_LIB_OVERRIDE"):
 
 MPG_OK = 0
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
-PREC_F16X1, PREC_F16F8, PREC_F16X3 = 1, 2, 3
-G8_F16, G8_F8C = 0, 1
+PREC_F16X1, PREC_F16F6, PREC_F16X3 = 1, 2, 3
+G8_F16 = 0
 MAX_SEG = 4
 
 _ACT_IDS = {None: ACT_NONE, "none": ACT_NONE, "relu": ACT_RELU, "lrelu": ACT_LRELU, "tanh": ACT_TANH}
@@ -42,7 +42,7 @@ class ConvSeg(ctypes.Structure):
         ("kh", ctypes.c_int32),
         ("kw", ctypes.c_int32),
         ("up_log2", ctypes.c_int32),
-        ("w_exp", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
         ("pad_hi", ctypes.c_int32),
     ]
 
@@ -65,7 +65,6 @@ class ConvDesc(ctypes.Structure):
         ("post_add_coff", ctypes.c_int32),
         ("y", ctypes.c_void_p),
         ("y_g8", ctypes.c_void_p),
-        ("y_g8c", ctypes.c_void_p),
         ("prec", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
         ("in_amax", ctypes.c_void_p),
@@ -88,7 +87,7 @@ PROTOTYPES = {
     "mpg_absmax": (_I, [_P, _P, _Z, _P]),
     "mpg_g8_to_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I]),
-    "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _I, _P, _Z]),
+    "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _Z]),
     "mpg_conv2d_fused": (_I, [_P, ctypes.POINTER(ConvDesc)]),
     "mpg_conv2d_direct": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _F, _P]),
     "mpg_resize_nearest": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),

@@ -33,28 +33,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_AH
 #define MPG_AH 2
 #endif
-// development switches of the F16F8 K loop (tools/build_variants.sh builds one library per setting, tools/probe_variants.py
-// times them against each other on one box):
-//   MPG_KASM 1:     the stage body issues its LDS fragment reads as explicit ds_read_b128 in program order, MPG_AH MFMA
-//                   groups ahead of their use, and waits with counted `s_waitcnt lgkmcnt(n)` tied to the fragment
-//                   (the compiler otherwise sinks the reads next to their use and waits with lgkmcnt(0): one full LDS
-//                   round trip exposed per group)
-#ifndef MPG_KASM
-#define MPG_KASM 1
-#endif
-//   MPG_STAMPS 1:   diagnostic build only: every wave accumulates, over the stages of its K loop, the s_memtime cycles
-//                   spent (0) from the barrier release to the end of its DMA issue, (1) in the fp16 groups, (2) in the
-//                   fp8 groups, (3) waiting at the `s_waitcnt vmcnt / s_barrier` of the next stage, and writes the four
-//                   sums to y[(block * WAVES + wave) * 4 ..] when desc.reserved has bit 3 set (tools/probe_stamps.py)
-#ifndef MPG_STAMPS
-#define MPG_STAMPS 0
-#endif
-//   MPG_DIAG 1 / 2 / 3: timing-only builds (results are garbage): 1 = no LDS fragment reads, 2 = no LDS-DMA pieces in the
-//                   stage loop, 3 = neither: what the MFMA issue structure alone costs
-#ifndef MPG_DIAG
-#define MPG_DIAG 0
-#endif
-
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
@@ -70,9 +48,9 @@ struct SegArgs {
     int hs, ws;           // source height / width (h >> up, w >> up)
     int np;               // pixels per image plane, padded to a multiple of 64
     int ni_img;           // image DMA instructions per thread per chunk
-    int sw_hi, sw_lo;     // F16F8: E8M0 scale words (replicated bytes) of the fp8 weight planes
-    int direct;           // F16F8, 1x1 over >= 2 groups: B fragments straight from memory, K runs over groups
-    int tp;               // F16F8: tap slots per channel group (kh*kw, or rounded up to 8 when below 16)
+    int direct;           // F16F6, 1x1 over >= 2 groups: B fragments straight from memory, K runs over groups
+    int tp;               // F16F6: tap slots per channel group (kh*kw, or rounded up to 8 when below 16)
+    int pref;             // F16F6: the B fragments of stage st + 1 may be read during stage st (seg_shape_f6)
 };
 
 struct ConvArgs {
@@ -87,11 +65,10 @@ struct ConvArgs {
     int pa_stride, pa_coff;
     float* y;             // fp32 NHWC output or null
     char* y_g8;           // G8 output (planes hi16, lo16) or null
-    char* y_g8c;          // G8 output in the F16F8 flavour (planes hi16, {hi8 | lo8}) or null
     const float* in_amax; // inputs were multiplied by pow2_scale(*in_amax): the accumulators are divided by it
     const char* zeros;    // >= 16 zero bytes (source of out-of-image pixels)
     int img_bytes;        // bytes of one LDS image buffer (max over segments)
-    int tap_bytes;        // F16F8: bytes of the two tap-offset tables at the start of LDS
+    int tap_bytes;        // F16F6: bytes of the tap-offset table at the start of LDS
     int tiles_x, tiles_y;
     int dbg;              // development probes: 1 skip K loop, 2 skip stores
 };
@@ -129,35 +106,6 @@ __device__ __forceinline__ void dma16(const char* src, char* lds_wave_base) {
     // lane l of the wave copies 16 bytes from its own `src` to lds_wave_base + 16*l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// fp8 (OCP e4m3) exponents of the activation planes of the F16F8 flavour: hi8 = fp8(v * 2^SA_HI),
-// lo8 = fp8((v - fp16(v)) * 2^SA_LO); the MFMA block scales undo them (E8M0 = 127 - S)
-constexpr int SA_HI = 2;
-constexpr int SA_LO = 13;
-
-__device__ __forceinline__ int pack4_fp8(float v0, float v1, float v2, float v3, float scale) {
-    // saturate to the e4m3 range before converting
-    const float lim = 448.f;
-    v0 = fminf(fmaxf(v0 * scale, -lim), lim);
-    v1 = fminf(fmaxf(v1 * scale, -lim), lim);
-    v2 = fminf(fmaxf(v2 * scale, -lim), lim);
-    v3 = fminf(fmaxf(v3 * scale, -lim), lim);
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(v0, v1, 0, false);
-    return __builtin_amdgcn_cvt_pk_fp8_f32(v2, v3, w, true);
-}
-
-// plane 1 of the F16F8 flavour for 8 channel values: bytes 0-7 hi8, bytes 8-15 lo8
-__device__ __forceinline__ int4 g8c_plane1(const float v[8]) {
-    float lo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) lo[j] = v[j] - (float)(_Float16)v[j];
-    int4 o;
-    o.x = pack4_fp8(v[0], v[1], v[2], v[3], (float)(1 << SA_HI));
-    o.y = pack4_fp8(v[4], v[5], v[6], v[7], (float)(1 << SA_HI));
-    o.z = pack4_fp8(lo[0], lo[1], lo[2], lo[3], (float)(1 << SA_LO));
-    o.w = pack4_fp8(lo[4], lo[5], lo[6], lo[7], (float)(1 << SA_LO));
-    return o;
 }
 
 template <int NT, int PT>
@@ -241,42 +189,24 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
                 }
             }
             if (a.y_g8 != nullptr) {
-                // lanes 0-31 write the hi plane, lanes 32-63 the lo plane of pixel r: 512-byte runs
-                const size_t plane_px = (size_t)a.h * a.w;
-                if (r < npx) {
-                    for (int cg = 0; cg < cg_out; ++cg) {
-                        const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
-                        const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
-                        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        half8 o;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const _Float16 hi = (_Float16)v[j];
-                            o[j] = hh ? (_Float16)(v[j] - (float)hi) : hi;
-                        }
-                        char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2 + hh) * plane_px + (size_t)py * a.w + x0 + r) * 16;
-                        *reinterpret_cast<half8*>(dst) = o;
-                    }
-                }
-            }
-            if (a.y_g8c != nullptr) {
-                // lane (pixel r, half hh) converts channel group 2 i + hh and writes BOTH of its planes (hi16, then
-                // {hi8 | lo8}): no divergence between the halves, 512-byte runs per plane and half-wave
+                // lane (pixel r, half hh) converts channel group 2 i + hh and writes BOTH of its planes (hi16, lo16): no
+                // divergence between the halves, 512-byte runs per plane and half-wave; streamed (read once or twice by
+                // the next launch), so the stores do not push the weights out of L2
                 const size_t plane_px = (size_t)a.h * a.w;
                 if (r < npx) {
                     for (int cg = hh; cg < cg_out; cg += 2) {
                         const float4 v0 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8);
                         const float4 v1 = *reinterpret_cast<const float4*>(stg + r * ROWF + cg * 8 + 4);
                         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                        char* dst = a.y_g8c + ((((size_t)n * cg_out + cg) * 2) * plane_px + (size_t)py * a.w + x0 + r) * 16;
-                        half8 o;
+                        char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                        half8 hi, lo;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (_Float16)v[j];
-                        __builtin_nontemporal_store(o, reinterpret_cast<half8*>(dst));
-                        typedef int v4i_t __attribute__((ext_vector_type(4)));
-                        const int4 p1 = g8c_plane1(v);
-                        v4i_t p1v = {p1.x, p1.y, p1.z, p1.w};
-                        __builtin_nontemporal_store(p1v, reinterpret_cast<v4i_t*>(dst + plane_px * 16));
+                        for (int j = 0; j < 8; ++j) {
+                            hi[j] = (_Float16)v[j];
+                            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+                        }
+                        __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(dst));
+                        __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(dst + plane_px * 16));
                     }
                 }
             }
@@ -433,32 +363,45 @@ __global__ __launch_bounds__(256, (NT >= 2 ? 2 : 3)) void conv_mfma_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------
-// MPG_PREC_F16F8: one fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and
-// a_hi*w_lo on the block-scaled fp8 path (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 operands, K = 64
-// per instruction at twice the fp16 rate per K).  The corrections only need ~4 bits: together the
-// three products are accurate to ~2^-15 per operand instead of fp16's 2^-11.
+// MPG_PREC_F16F6: one fp16 product a_hi*w_hi plus the two correction products a_lo*w_hi and a_hi*w_lo as
+// block-scaled bf6 (e3m2) products: v_mfma_scale_f32_32x32x64_f8f6f4 with cbsz = blgp = 3 runs K = 64 in the
+// 32 cycles of ONE fp16 32x32x16 (K = 16), so the two corrections cost half an fp16 product together:
+// 1.5 fp16-equivalent matrix units per MAC (the fp8 form of round 1-2 cost 2: a mixed or fp8 operand pair
+// runs at half this rate; tools/probes/probe_bf6.hip).
+//
+// Activations are read in the exact G8 flavour (hi16, lo16).  The bf6 operands of a lane -- the 32 K values
+// (4 tap slots x 8 channels) it holds for the K = 64 instruction -- are made in registers from the very fp16
+// fragments the fp16 products use: v_cvt_scalef32_pk32_bf6_f16 converts 32 values in one instruction with a
+// power-of-two block scale, which is PER LANE here: 2^-18 times the binade of the largest |a_hi| among the
+// lane's 32 values (three-input packed max / min trees), and 2^-12 of that for the a_lo block.  The E8M0
+// bytes of both go to the MFMA's scale operand: true MX block scaling, no per-tensor exponent, nothing the
+// producer has to know -- an activation tensor of any range and any mix of channel scales keeps the
+// corrections (the fixed exponents of the fp8 flavour lost them outside |v| in 1e-2..112).
+// Weights: bf6 planes packed per stage with one E8M0 byte per (output channel, K block of 32) and plane.
+//
 // One workgroup = WAVES waves = 16 tile rows x 32 pixels; a weight stage is one macro-step of 8 tap slots
-// (K = 64): [4 fp16 k-steps][w_hi8][w_lo8].  The slots of a segment form one stream over its channel groups
+// (K = 64): [4 fp16 k-steps][w_hi6][w_lo6].  The slots of a segment form one stream over its channel groups
 // (slot = group * tp + tap), so a stage may end one group and begin the next; every group has its own LDS image.
 // ---------------------------------------------------------------------------------------------
+typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v6i __attribute__((ext_vector_type(6)));
 // LDS reads in the K loops use clang vector types only: a read through HIP's struct `int4` makes the compiler put an
 // `s_waitcnt vmcnt(0)` in front of it while LDS-DMA pieces are in flight (it cannot tell the read from the DMA's
 // destination), which serialises every stage behind its own weight / image DMAs; ext_vector_type reads do not.
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v2i __attribute__((ext_vector_type(2)));
+typedef _Float16 half32 __attribute__((ext_vector_type(32)));
+typedef _Float16 half16 __attribute__((ext_vector_type(16)));
 
-// 32 bytes of LDS as two 16-byte reads: a single v8i (32-byte) read is split by the compiler into two ds_read_b128
-// that again carry the conservative `s_waitcnt vmcnt(0)` against pending LDS-DMA
-// The two halves of a lane's 32 bytes sit 1 KiB apart ([half][lane][16 B]): consecutive lanes read consecutive
-// 16-byte words, which ds_read_b128 serves without bank conflicts (a [lane][32 B] layout is 2-way conflicted).
+// 32 bytes of LDS as two 16-byte reads ([half][lane][16 B]: consecutive lanes read consecutive 16-byte words,
+// which ds_read_b128 serves without bank conflicts; a [lane][32 B] layout is 2-way conflicted)
 __device__ __forceinline__ v8i lds_read32(const char* p) {
     const v4i lo = *reinterpret_cast<const v4i*>(p);
     const v4i hi = *reinterpret_cast<const v4i*>(p + 1024);
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// ---- explicit LDS reads / counted waits (MPG_KASM) ----
+// ---- explicit LDS reads / counted waits ----
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -469,58 +412,88 @@ __device__ __forceinline__ void static_for(F&& f) {
 __device__ __forceinline__ unsigned lds_off(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
+// The reads and waits are volatile asm: they stay in program order, which is what the counted waits count.
 template <int OFF, class T>
 __device__ __forceinline__ void ds_read16(T& dst, unsigned addr) {
     static_assert(sizeof(T) == 16 && OFF >= 0 && OFF < 65536, "one ds_read_b128");
-#if MPG_DIAG & 1
-    asm volatile("" : "=v"(dst) : "v"(addr));
-#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-#endif
 }
-template <int OFF, class T>
-__device__ __forceinline__ void ds_read8(T& dst, unsigned addr) {
-    static_assert(sizeof(T) == 8 && OFF >= 0 && OFF < 65536, "one ds_read_b64");
-#if MPG_DIAG & 1
-    asm volatile("" : "=v"(dst) : "v"(addr));
-#else
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-#endif
+// wait until at most N of the LDS reads issued so far are outstanding (they return in order)
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
 }
-// wait until at most N of the LDS reads issued so far are outstanding (they return in order); tying the wait to the
-// fragment keeps every instruction that consumes it behind the wait
-template <int N, class T>
-__device__ __forceinline__ void lgkm_wait(T& frag) {
-    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N < 15 ? N : 15));
+// no instruction: makes every later use of `frag` depend on the preceding (volatile) wait
+template <class T>
+__device__ __forceinline__ void tie(T& frag) {
+    asm volatile("" : "+v"(frag));
 }
 
 // bookkeeping of the explicit schedule (all compile-time): fp16 group h = (k-step h / NT, cout tile h % NT) issues
-// [PT B fragments when h % NT == 0] + 1 A fragment; the fp8 operands ride behind the last four groups
+// [PT B fragments when h % NT == 0] + 1 A fragment
 constexpr int kx_cum(int h, int NT, int PT) { return h + PT * ((h + NT - 1) / NT); }
-constexpr int kx_extra(int g, int NT, int PT) {
-    const int G16 = 4 * NT;
-    if (g < G16 - 4) return 0;
-    int e = 2 * PT * (g - (G16 - 4) + 1);
-    if (g >= G16 - 2) e += 4;
-    if (g >= G16 - 1 && NT > 1) e += 4;
-    return e;
-}
 // reads that may still be outstanding when group g's MFMAs start: everything issued after group g's own fragments
 constexpr int kx_allowed(int g, int NT, int PT, int AH) {
     const int G16 = 4 * NT;
     const int hi = g + AH + 1 < G16 ? g + AH + 1 : G16;
-    const int e0 = g - AH - 1;
-    return (kx_cum(hi, NT, PT) - kx_cum(g + 1, NT, PT)) + (kx_extra(g, NT, PT) - (e0 >= 0 ? kx_extra(e0, NT, PT) : 0));
+    return kx_cum(hi, NT, PT) - kx_cum(g + 1, NT, PT);
 }
 
+__device__ __forceinline__ half32 cat32(const half8& a, const half8& b, const half8& c, const half8& d) {
+    const half16 lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const half16 hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23,
+                                   24, 25, 26, 27, 28, 29, 30, 31);
+}
+
+// biased fp16 exponent (0..30) of the largest |x| among the 32 halves of a lane: packed three-input max and min
+// trees (8 + 8 instructions; v_pk_maximum3_f16 has no |x| modifier), max(max, -min), the larger half, its exponent
+__device__ __forceinline__ int block_exp16(const half32& v) {
+    const v16i r = __builtin_bit_cast(v16i, v);
+    int a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7, m2, m1;
+#define MPG_MAX3(d, x, y, z) asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z))
+#define MPG_MIN3(d, x, y, z) asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z))
+    MPG_MAX3(a0, r[0], r[1], r[2]); MPG_MAX3(a1, r[3], r[4], r[5]); MPG_MAX3(a2, r[6], r[7], r[8]); MPG_MAX3(a3, r[9], r[10], r[11]);
+    MPG_MAX3(a4, r[12], r[13], r[14]); MPG_MAX3(a5, a0, a1, r[15]); MPG_MAX3(a6, a2, a3, a4); MPG_MAX3(a7, a5, a6, a6);
+    MPG_MIN3(b0, r[0], r[1], r[2]); MPG_MIN3(b1, r[3], r[4], r[5]); MPG_MIN3(b2, r[6], r[7], r[8]); MPG_MIN3(b3, r[9], r[10], r[11]);
+    MPG_MIN3(b4, r[12], r[13], r[14]); MPG_MIN3(b5, b0, b1, r[15]); MPG_MIN3(b6, b2, b3, b4); MPG_MIN3(b7, b5, b6, b6);
+#undef MPG_MAX3
+#undef MPG_MIN3
+    asm("v_pk_max_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(m2) : "v"(a7), "v"(b7));
+    asm("v_pk_max_f16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(m1) : "v"(m2));
+    return (m1 >> 10) & 31;
+}
+
+// bf6 operands of a lane's 32 activation values.  With e = block_exp16 (every |a_hi| < 2^(e-14)):
+//   hi block: codes of a_hi * 2^(18-e)  (< 16; the e3m2 range ends at 28), E8M0 byte e + 109
+//   lo block: codes of a_lo * 2^(30-e)  (|a_lo| <= half an ulp of a_hi <= 2^(e-26)), E8M0 byte e + 97
+// v_cvt_scalef32_pk32_bf6_f16 divides by its f32 scale operand (a power of two), rounds to nearest even and saturates.
+#ifndef MPG_CVT_DIVIDES
+#define MPG_CVT_DIVIDES 1
+#endif
+__device__ __forceinline__ float pow2_from_byte(int e8m0) {
+#if MPG_CVT_DIVIDES
+    return __builtin_bit_cast(float, e8m0 << 23);
+#else
+    return __builtin_bit_cast(float, (254 - e8m0) << 23);
+#endif
+}
+__device__ __forceinline__ v8i widen6(const v6i& v) {
+    return __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, -1, -1);
+}
+__device__ __forceinline__ v8i bf6_of(const half32& v, int e8m0) {
+    return widen6(__builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v, pow2_from_byte(e8m0)));
+}
+constexpr int BF6 = 3;     // cbsz / blgp code of e3m2
+
 template <int NT>
-struct Pipe8 {
+struct Pipe6 {
     static constexpr int WAVES = (NT == 1) ? 4 : 8;
     static constexpr int PT = 16 / WAVES;                  // tile rows per wave
     static constexpr int TH = 16;
     static constexpr int WF16 = 4 * NT * 1024;             // four fp16 k-steps
-    static constexpr int WF8 = NT * 2048;                  // one fp8 plane: NT x 64 lanes x 32 B
-    static constexpr int WSTAGE = WF16 + 2 * WF8;          // 8 * NT KiB
+    static constexpr int WF6 = NT * 2048;                  // one bf6 plane: NT x [2 halves][64 lanes][16 B]: 24 B of codes, scales, pad
+    static constexpr int WSTAGE = WF16 + 2 * WF6;          // 8 * NT KiB
     static constexpr int R = 3;
     static constexpr int D = R - 1;
     static constexpr int NI = WSTAGE / (WAVES * 1024);
@@ -528,16 +501,15 @@ struct Pipe8 {
 };
 
 template <int NT>
-__global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(const ConvArgs a_unused) {
+__global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(const ConvArgs a_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const auto& a = *ap;
-    using P = Pipe8<NT>;
-    constexpr int WAVES = P::WAVES, PT = P::PT, TH = P::TH, WF16 = P::WF16, WF8 = P::WF8, WSTAGE = P::WSTAGE;
+    using P = Pipe6<NT>;
+    constexpr int WAVES = P::WAVES, PT = P::PT, TH = P::TH, WF16 = P::WF16, WF6 = P::WF6, WSTAGE = P::WSTAGE;
     constexpr int NI = P::NI, R = P::R, D = P::D, THREADS = WAVES * 64;
 
-    int* tapoff = reinterpret_cast<int*>(smem);
-    int* tap16 = reinterpret_cast<int*>(smem + (a.tap_bytes >> 1));
+    int* tap16 = reinterpret_cast<int*>(smem);
     char* img_lds = smem + a.tap_bytes;
     char* w_lds = img_lds + 2 * a.img_bytes;
 
@@ -564,9 +536,6 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[pt][nt][i] = 0.f;
-
-    const int sa_hi = (127 - SA_HI) * 0x01010101;
-    const int sa_lo = (127 - SA_LO) * 0x01010101;
 
     // The K segments are independent partial sums.  Blocks that share a CU (workgroups go round-robin over the 8
     // XCDs, then over the 32 CUs of an XCD: co-resident blocks differ in bit 8 of the id) walk them in opposite
@@ -607,52 +576,46 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 const char* wb = w_lds + (st % R) * WSTAGE;
                 const char* xs = xb + (size_t)st * 8 * gstride;   // uniform: first group of this macro-step
                 const int grem = glast - st * 8;
-                half8 b_hi[4][PT];
-                v8i b8_hi[PT], b8_lo[PT];
+                half8 b_hi[4][PT], b_lo[4][PT];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int g = 2 * j + hh;
                     g = g < grem ? g : grem;                 // groups past the segment: zero weights
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
+                    for (int pt = 0; pt < PT; ++pt) {
                         b_hi[j][pt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride)));   // read once
-                }
-                {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int g = 4 * hh + i;
-                        g = g < grem ? g : grem;
-#pragma unroll
-                        for (int pt = 0; pt < PT; ++pt) {
-                            typedef int v4i_t __attribute__((ext_vector_type(4)));
-                            const v4i_t v = __builtin_nontemporal_load(reinterpret_cast<const v4i_t*>(xs + (pixo[pt] + g * gstride + plane_bytes)));
-                            b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
-                            b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
-                        }
+                        b_lo[j][pt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride + plane_bytes)));
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
 #pragma unroll
-                            for (int pt = 0; pt < PT; ++pt)
-                                acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[j][pt], acc[pt][nt], 0, 0, 0);
-                        }
+                        for (int pt = 0; pt < PT; ++pt)
+                            acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[j][pt], acc[pt][nt], 0, 0, 0);
                     }
+                }
+                v8i hi6[PT], lo6[PT];
+                int sb[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    const half32 bh = cat32(b_hi[0][pt], b_hi[1][pt], b_hi[2][pt], b_hi[3][pt]);
+                    const half32 bl = cat32(b_lo[0][pt], b_lo[1][pt], b_lo[2][pt], b_lo[3][pt]);
+                    const int e = block_exp16(bh);
+                    hi6[pt] = bf6_of(bh, e + 109);
+                    lo6[pt] = bf6_of(bl, e + 97);
+                    sb[pt] = (e + 109) | (e + 97) << 8;
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const v8i w8_hi = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
-                    const v8i w8_lo = lds_read32(wb + WF16 + WF8 + nt * 2048 + lane * 16);
+                    const v8i w_hi = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
+                    const v8i w_lo = lds_read32(wb + WF16 + WF6 + nt * 2048 + lane * 16);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) {
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_hi, b8_lo[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sg.sw_hi, 0, sa_lo);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8_lo, b8_hi[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sg.sw_lo, 0, sa_hi);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_lo, hi6[pt], acc[pt][nt], BF6, BF6, 1, w_lo[6], 0, sb[pt]);
+                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_hi, lo6[pt], acc[pt][nt], BF6, BF6, 0, w_hi[6], 1, sb[pt]);
                     }
                 }
             }
@@ -663,17 +626,12 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
         // K is ONE stream of tap slots over the channel groups of the segment: slot q = (group q / tp, tap q % tp),
         // eight slots per weight stage, so a stage may finish one group and start the next (25 taps x 16 groups =
         // 50 full stages instead of 16 x 4 with 7 empty slots each).  Group g's halo image lives in LDS buffer
-        // g & 1; the offset tables carry the buffer with the tap.
+        // g & 1; the offset table carries the buffer with the tap.
         const int T = sg.kh * sg.kw;
         const int G = sg.nchunks;
         const int NS = sg.sc;
         const int plane_b = sg.np * 16;
         const int ppg = sg.np >> 6;
-        // the E8M0 scale words of the weight planes live in VGPRs across the K loop: as scalars they are spilled and
-        // re-loaded from the kernarg segment every stage, and the `s_waitcnt lgkmcnt(0)` of that scalar load drains
-        // the whole LDS read pipeline in the middle of the stage
-        int sw_hi_v = sg.sw_hi, sw_lo_v = sg.sw_lo;
-        asm volatile("" : "+v"(sw_hi_v), "+v"(sw_lo_v));
 
         for (int q = tid; q < NS * 8; q += THREADS) {
             const int g = q / sg.tp;
@@ -684,40 +642,13 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                 const int dx = t - dy * sg.kw;
                 off = (g & 1) * a.img_bytes + (dy * sg.iw + dx) * 16;
             }
-            tapoff[q] = off;                                                        // fp8 order: slot
-            tap16[(q >> 3) * 8 + (q & 1) * 4 + ((q & 7) >> 1)] = off;             // fp16 order: [stage][half][k-step]
+            tap16[(q >> 3) * 8 + (q & 1) * 4 + ((q & 7) >> 1)] = off;             // [stage][half][k-step]
         }
         int pixb[PT];
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) pixb[pt] = ((PT * wave + pt) * sg.iw + r) * 16;
 
         const size_t plane_px = (size_t)sg.hs * sg.ws;
-        [[maybe_unused]] auto dma_image = [&](int chunk) {
-            char* buf = img_lds + (chunk & 1) * a.img_bytes;
-            for (int i = 0; i < sg.ni_img; ++i) {
-                const int pc = WAVES * i + wave_u;
-                const int pl = pc / ppg;                       // plane: 0 hi16, 1 {hi8|lo8}
-                const int p = (pc - pl * ppg) * 64 + lane;
-                const int hy = p / sg.iw;
-                const int hx = p - hy * sg.iw;
-                const int yy = y0 - sg.pt + hy;
-                const int xx = x0 - sg.pl + hx;
-                const char* src = a.zeros;
-                if (pl < 2 && chunk < sg.cg_seg && hy < sg.ih && yy >= 0 && yy < a.h && xx >= 0 && xx < a.w)
-                    src = sg.x + ((((size_t)n * sg.cg_total + sg.g_off + chunk) * 2 + pl) * plane_px +
-                                  (size_t)(yy >> sg.up) * sg.ws + (xx >> sg.up)) * 16;
-                dma16_stream(src, buf + pc * 1024);
-            }
-        };
-        auto dma_stage = [&](int stage) {
-            const int sidx = stage < NS ? stage : NS - 1;
-            const char* src = sg.w + (size_t)sidx * WSTAGE + tid * 16;
-            char* dst = w_lds + (stage % R) * WSTAGE + wave_u * 1024;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) dma16(src + i * (THREADS * 16), dst + i * (THREADS * 16));
-        };
-
-#if MPG_KASM
         // Every group's image has the same per-lane source offsets (only the group's base address differs): they are
         // worked out once per segment, so that inside the stage loop an image piece costs a select and one DMA
         // instruction.  -1: the pixel lies outside the image (or past the halo rows): it is fetched from the zero page.
@@ -753,316 +684,229 @@ __global__ __launch_bounds__(Pipe8<NT>::WAVES * 64, 2) void conv_mfma_f8_kernel(
                   w_lds + (stage % R) * WSTAGE + wave_u * 1024 + i * (THREADS * 16));
         };
         static_for<0, MAXI>([&](auto ic) { img_piece(0, ic); });
-#else
-        dma_image(0);
-#endif
 #pragma unroll
-        for (int d = 0; d < D; ++d) dma_stage(d);
+        for (int d = 0; d < D; ++d) static_for<0, NI>([&](auto ic) { w_piece(d, ic); });
         int g_next = 1;                                  // next group image to fetch
-        const char* img = img_lds;
-#if MPG_STAMPS
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts3_prev = 0;
-        unsigned sum_dma = 0, sum_f16 = 0, sum_f8 = 0, sum_bar = 0;
-#define MPG_STAMP(v) asm volatile("s_memtime %0" : "=s"(v))
-#else
-#define MPG_STAMP(v)
-#endif
 
-#if MPG_KASM
-        v4i o16n = {0, 0, 0, 0}, o8n = {0, 0, 0, 0};
-#endif
+        // B fragments of a stage: lane (pixel r of tile row pt, half hh) holds, for k-step j, the 8 channels of slot
+        // 2 j + hh: bh[pt][j] is both the fp16 B operand of k-step j and a quarter of the lane's bf6 block.
+        half8 bh[PT][4];
+        v4i o16n = {0, 0, 0, 0};
+        const unsigned i_base = lds_off(img_lds);
+
         for (int st = 0; st < NS; ++st) {
             // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
             // with stage st-1
             wait_dma_and_barrier<(D - 1) * NI>();
-#if MPG_STAMPS
-            // the barrier's lgkmcnt(0) completed every stamp of the previous stage
-            if (st > 0) {
-                sum_dma += (unsigned)(ts1 - ts0);
-                sum_f16 += (unsigned)(ts2 - ts1);
-                sum_f8 += (unsigned)(ts3 - ts2);
-                if (st > 1) sum_bar += (unsigned)(ts0 - ts3_prev);
-                ts3_prev = ts3;
-            }
-            MPG_STAMP(ts0);
-#endif
-            // tap offsets of the whole stage in two 16-byte reads, before this stage's DMAs are issued (the compiler
-            // orders LDS reads behind pending LDS-DMA writes)
-#if MPG_KASM
-            // the tap tables are constant over the segment: stage st + 1's entries are read at the head of stage st (the
-            // first LDS reads of the stage, so every counted wait below sees them as older than what it waits for) and
-            // the barrier's lgkmcnt(0) has completed them when the next stage starts
+            // the tap table is constant over the segment: stage st + 1's entry is read at the head of stage st
             if (st == 0) {
                 ds_read16<0>(o16n, lds_off(tap16 + hh * 4));
-                ds_read16<0>(o8n, lds_off(tapoff + 4 * hh));
-                lgkm_wait<0>(o16n);
-                lgkm_wait<0>(o8n);
+                lgkm_wait<0>();
             }
-            const v4i o16 = o16n, o8 = o8n;
+            tie(o16n);
+            const v4i o16 = o16n;
+            const int to16[4] = {o16.x, o16.y, o16.z, o16.w};
             {
                 const int sn = st + 1 < NS ? st + 1 : st;
                 ds_read16<0>(o16n, lds_off(tap16 + (sn * 2 + hh) * 4));
-                ds_read16<0>(o8n, lds_off(tapoff + sn * 8 + 4 * hh));
             }
-#else
-            const v4i o16 = *reinterpret_cast<const v4i*>(tap16 + (st * 2 + hh) * 4);
-            const v4i o8 = *reinterpret_cast<const v4i*>(tapoff + st * 8 + 4 * hh);
-            asm volatile("" ::"v"(o16.x), "v"(o16.y), "v"(o16.z), "v"(o16.w), "v"(o8.x), "v"(o8.y), "v"(o8.z), "v"(o8.w));
-#endif
             // image of group g_next goes into the buffer of group g_next - 2: free once no slot of this or a later
-            // stage belongs to that group; it is first read >= 1 stage later (tp >= 8), i.e. behind >= D-1 ring stages
-#if !MPG_KASM
-            auto issue_dma = [&]() {
-                if (g_next < G && st * 8 >= (g_next - 1) * sg.tp) {
-                    dma_image(g_next);
-                    ++g_next;
-                }
-                dma_stage(st + D);
-            };
-#endif
-#if MPG_KASM
-            // The LDS-DMA pieces of this stage are spread over its MFMA groups (one piece at a time between the MFMAs)
-            // instead of being issued as a burst behind the barrier: a burst of WAVES x (NI + image pieces) 1-KiB
-            // pieces queues up in the CU's address unit for ~1000-1500 cycles in which no wave issues an MFMA
-            // (measured with MPG_STAMPS).  Order within the stage: the image pieces in the first half of the groups,
-            // then the NI weight pieces of stage st + D, so `vmcnt((D-1) NI)` at the next barrier still covers them.
+            // stage belongs to that group.  The LDS-DMA pieces of this stage are spread over its MFMA groups (one piece
+            // at a time between the MFMAs) instead of being issued as a burst behind the barrier: a burst of WAVES x
+            // (NI + image pieces) 1-KiB pieces queues up in the CU's address unit for ~1000-1500 cycles in which no
+            // wave issues an MFMA (profiles/r02/kloop_analysis.md).  Order within the stage: the image pieces in the
+            // first half of the groups, then the NI weight pieces of stage st + D, so `vmcnt((D-1) NI)` at the next
+            // barrier still covers them.
             const bool do_img = g_next < G && st * 8 >= (g_next - 1) * sg.tp;
             const int img_chunk = g_next;
             if (do_img) ++g_next;
-            // (tried: letting these image pieces stay in flight across the next barrier when their first reader is a later
-            // stage, with a vmcnt chosen per stage: +2 % time -- the extra branch costs more than the wait it removes)
-#else
-            issue_dma();
-#endif
-            MPG_STAMP(ts1);
             const char* wb = w_lds + (st % R) * WSTAGE;
-            const int to16[4] = {o16.x, o16.y, o16.z, o16.w};
-            const int to8[4] = {o8.x, o8.y, o8.z, o8.w};
-#if MPG_KASM
-            {
-                constexpr int AH = MPG_AH, G16 = 4 * NT;
-                constexpr int NB = (AH + NT - 1) / NT + 1;     // k-steps of B fragments alive: the current one + the look-ahead
-                half8 aq[AH + 1], bq[NB][PT];
-                v2i b8h[PT][4], b8l[PT][4];                      // fp8 B operands: taps 4 hh + i, {hi8 | lo8} of 8 channels each
-                v4i wq[2][2][2];                                 // [buffer][plane hi / lo][half of the lane's 32 bytes]
-                const unsigned a_base = lds_off(wb) + (unsigned)lane * 16u;
-                const unsigned i_base = lds_off(img);
-                unsigned b_addr[4][PT], b8_addr[4][PT];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        b_addr[j][pt] = i_base + (unsigned)(pixb[pt] + to16[j]);
-                        b8_addr[j][pt] = i_base + (unsigned)(plane_b + pixb[pt] + to8[j]);
-                    }
-                auto read_group = [&](auto gc) {
-                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                    if constexpr (nt == 0)
-                        static_for<0, PT>([&](auto pc) {
-                            constexpr int pt = decltype(pc)::value;
-                            ds_read16<0>(bq[j % NB][pt], b_addr[j][pt]);
+            const unsigned a_base = lds_off(wb) + (unsigned)lane * 16u;
+            constexpr int AH = MPG_AH, G16 = 4 * NT;
+            half8 aq[AH + 1];
+            v8i hi6[PT], lo6[PT];
+            int sb[PT], e16[PT];
+            // fp16 group g = (k-step g / NT, cout tile g % NT): its reads are [the PT B fragments of the k-step when
+            // g % NT == 0] + one A fragment, issued AH groups ahead of its MFMAs
+            auto read_group = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, j = g / NT;
+                if constexpr (g % NT == 0)
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(pixb[pt] + to16[j]));
+                    });
+                ds_read16<g * 1024>(aq[g % (AH + 1)], a_base);
+            };
+            auto make_hi6 = [&](auto pc) {
+                constexpr int pt = decltype(pc)::value;
+                const half32 b32 = cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]);
+                e16[pt] = block_exp16(b32);
+                hi6[pt] = bf6_of(b32, e16[pt] + 109);
+                sb[pt] = (e16[pt] + 109) | (e16[pt] + 97) << 8;
+            };
+            static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
+            constexpr int HALF = G16 / 2;
+            constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
+            constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
+            // ---- the fp16 product: G16 groups of PT MFMAs ----
+            static_for<0, G16>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
+                if constexpr (g < HALF) {
+                    if (do_img)
+                        static_for<0, IPG>([&](auto kc) {
+                            constexpr int i = g * IPG + decltype(kc)::value;
+                            if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
                         });
-                    ds_read16<(j * NT + nt) * 1024>(aq[g % (AH + 1)], a_base);
-                };
-                auto read_w8 = [&](auto nc) {
-                    constexpr int nt = decltype(nc)::value;
-                    ds_read16<WF16 + nt * 2048>(wq[nt & 1][0][0], a_base);
-                    ds_read16<WF16 + nt * 2048 + 1024>(wq[nt & 1][0][1], a_base);
-                    ds_read16<WF16 + WF8 + nt * 2048>(wq[nt & 1][1][0], a_base);
-                    ds_read16<WF16 + WF8 + nt * 2048 + 1024>(wq[nt & 1][1][1], a_base);
-                };
-                auto read_b8 = [&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    static_for<0, PT>([&](auto pc) {
-                        constexpr int pt = decltype(pc)::value;
-                        ds_read8<0>(b8h[pt][i], b8_addr[i][pt]);
-                        ds_read8<8>(b8l[pt][i], b8_addr[i][pt]);
+                } else {
+                    static_for<0, WPG>([&](auto kc) {
+                        constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
+                        if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
                     });
-                };
-                static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
-                constexpr int HALF = G16 / 2;
-                constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
-                constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
-                static_for<0, G16>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                    if constexpr ((MPG_DIAG & 2) != 0) {
-                    } else if constexpr (g < HALF) {
-                        if (do_img)
-                            static_for<0, IPG>([&](auto kc) {
-                                constexpr int i = g * IPG + decltype(kc)::value;
-                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
-                            });
-                    } else {
-                        static_for<0, WPG>([&](auto kc) {
-                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
-                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
-                        });
-                    }
-                    if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
-                    // the correction operands ride behind the last fp16 groups
-                    if constexpr (g >= G16 - 4) read_b8(std::integral_constant<int, g - (G16 - 4)>{});
-                    if constexpr (g == G16 - 2) read_w8(std::integral_constant<int, 0>{});
-                    if constexpr (g == G16 - 1 && NT > 1) read_w8(std::integral_constant<int, 1>{});
-                    constexpr int N = kx_allowed(g, NT, PT, AH);
-                    lgkm_wait<N>(aq[g % (AH + 1)]);
-                    static_for<0, PT>([&](auto pc) {
-                        constexpr int pt = decltype(pc)::value;
-                        lgkm_wait<N>(bq[j % NB][pt]);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bq[j % NB][pt], acc[pt][nt], 0, 0, 0);
-                    });
-                });
-                MPG_STAMP(ts2);
-                static_for<0, NT>([&](auto nc) {
-                    constexpr int nt = decltype(nc)::value;
-                    constexpr int N8 = (nt + 1 < NT) ? 4 : 0;     // only the next cout tile's weight planes may be in flight
-                    static_for<0, 2>([&](auto hc) {
-                        lgkm_wait<N8>(wq[nt & 1][0][decltype(hc)::value]);
-                        lgkm_wait<N8>(wq[nt & 1][1][decltype(hc)::value]);
-                    });
-                    const v8i w_hi = __builtin_shufflevector(wq[nt & 1][0][0], wq[nt & 1][0][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    const v8i w_lo = __builtin_shufflevector(wq[nt & 1][1][0], wq[nt & 1][1][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    static_for<0, PT>([&](auto pc) {
-                        constexpr int pt = decltype(pc)::value;
-                        if constexpr (nt == 0)
-                            static_for<0, 4>([&](auto ic) {
-                                lgkm_wait<N8>(b8h[pt][decltype(ic)::value]);
-                                lgkm_wait<N8>(b8l[pt][decltype(ic)::value]);
-                            });
-                        const v4i h01 = __builtin_shufflevector(b8h[pt][0], b8h[pt][1], 0, 1, 2, 3);
-                        const v4i h23 = __builtin_shufflevector(b8h[pt][2], b8h[pt][3], 0, 1, 2, 3);
-                        const v4i l01 = __builtin_shufflevector(b8l[pt][0], b8l[pt][1], 0, 1, 2, 3);
-                        const v4i l23 = __builtin_shufflevector(b8l[pt][2], b8l[pt][3], 0, 1, 2, 3);
-                        const v8i bh = __builtin_shufflevector(h01, h23, 0, 1, 2, 3, 4, 5, 6, 7);
-                        const v8i bl = __builtin_shufflevector(l01, l23, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_hi, bl, acc[pt][nt], 0, 0, 0, sw_hi_v, 0, sa_lo);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_lo, bh, acc[pt][nt], 0, 0, 0, sw_lo_v, 0, sa_hi);
-                    });
-                    if constexpr (nt + 2 < NT) read_w8(std::integral_constant<int, nt + 2>{});
-                });
-                MPG_STAMP(ts3);
-            }
-#else
-            {
-                // software-pipelined by hand: every fragment is read from LDS two MFMA groups (one group = the PT
-                // MFMAs of one weight fragment) before the group that consumes it
-                constexpr int AH = MPG_AH;    // read-ahead distance in MFMA groups
-                half8 bq[AH + 1][PT], aq[AH + 1];   // (with one cout tile, AH groups ahead is AH k-steps ahead)
-                v8i b8_hi[PT], b8_lo[PT], wq[2][2];
-                auto read_group = [&](int g) {            // operands of fp16 group g = k-step * NT + cout tile
-                    const int j = g / NT, nt = g % NT;
-                    if (nt == 0) {
-#pragma unroll
-                        for (int pt = 0; pt < PT; ++pt)
-                            bq[j % (AH + 1)][pt] = *reinterpret_cast<const half8*>(img + pixb[pt] + to16[j]);
-                    }
-                    aq[g % (AH + 1)] = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
-                };
-                auto read_w8 = [&](int nt) {
-                    wq[nt & 1][0] = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
-                    wq[nt & 1][1] = lds_read32(wb + WF16 + WF8 + nt * 2048 + lane * 16);
-                };
-                auto read_b8 = [&](int i) {
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        const v4i v = *reinterpret_cast<const v4i*>(img + plane_b + pixb[pt] + to8[i]);
-                        b8_hi[pt][2 * i] = v.x; b8_hi[pt][2 * i + 1] = v.y;
-                        b8_lo[pt][2 * i] = v.z; b8_lo[pt][2 * i + 1] = v.w;
-                    }
-                };
-#pragma unroll
-                for (int g = 0; g < AH; ++g) read_group(g);
-#pragma unroll
-                for (int g = 0; g < 4 * NT; ++g) {
-                    if (g + AH < 4 * NT) read_group(g + AH);
-                    // the correction operands ride behind the last fp16 groups
-                    if (g >= 4 * NT - 4) read_b8(g - (4 * NT - 4));
-                    if (g == 4 * NT - 2) read_w8(0);
-                    if (g == 4 * NT - 1 && NT > 1) read_w8(1);
-                    const int j = g / NT, nt = g % NT;
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bq[j % (AH + 1)][pt], acc[pt][nt], 0, 0, 0);
                 }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][0], b8_lo[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sw_hi_v, 0, sa_lo);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wq[nt & 1][1], b8_hi[pt], acc[pt][nt], 0, 0, 0,
-                                                                                   sw_lo_v, 0, sa_hi);
+                if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
+                lgkm_wait<kx_allowed(g, NT, PT, AH)>();        // reads issued behind group g's own
+                tie(aq[g % (AH + 1)]);
+                if constexpr (nt == 0)
+                    static_for<0, PT>([&](auto pc) { tie(bh[decltype(pc)::value][j]); });
+                static_for<0, PT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
+                });
+                // the a_hi block scales and codes (VALU work under the matrix pipe): tile row g - 3 NT behind each group of
+                // the last k-step, whatever is left behind the last group
+                if constexpr (g >= 3 * NT && g - 3 * NT < PT) make_hi6(std::integral_constant<int, g - 3 * NT>{});
+                if constexpr (g == G16 - 1 && NT < PT) static_for<NT, PT>([&](auto pc) { make_hi6(pc); });
+            });
+            // ---- the two bf6 corrections: step k < NT is w_lo6[k] x a_hi6, step k >= NT is w_hi6[k - NT] x a_lo6 ----
+            // LDS reads in order: W(0), the a_lo fragments of the first two tile rows (into the registers of their a_hi
+            // ones, which the conversions above have consumed), W(1), then W(k + 1) ahead of step k.
+            constexpr int PB = PT < 2 ? PT : 2;
+            v4i wq[2][2];
+            auto read_w6 = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int off = WF16 + (k < NT ? WF6 + k * 2048 : (k - NT) * 2048);
+                ds_read16<off>(wq[k & 1][0], a_base);
+                ds_read16<off + 1024>(wq[k & 1][1], a_base);
+            };
+            auto read_bl = [&](auto pc) {
+                constexpr int pt = decltype(pc)::value;
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    ds_read16<0>(bh[pt][j], i_base + (unsigned)(plane_b + pixb[pt] + to16[j]));
+                });
+            };
+            auto make_lo6 = [&](auto pc) {
+                constexpr int pt = decltype(pc)::value;
+                static_for<0, 4>([&](auto jc) { tie(bh[pt][decltype(jc)::value]); });
+                lo6[pt] = bf6_of(cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]), e16[pt] + 97);
+            };
+            read_w6(std::integral_constant<int, 0>{});
+            static_for<0, PB>([&](auto pc) { read_bl(pc); });
+            read_w6(std::integral_constant<int, 1>{});
+            static_for<0, 2 * NT>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k >= 1 && k + 1 < 2 * NT) read_w6(std::integral_constant<int, k + 1>{});
+                lgkm_wait<(k == 0 ? 4 * PB + 2 : (k + 1 < 2 * NT ? 2 : 0))>();
+                tie(wq[k & 1][0]);
+                tie(wq[k & 1][1]);
+                if constexpr (k == 1) {
+                    static_for<0, PB>([&](auto pc) { make_lo6(pc); });
+                    if constexpr (PT > PB) {           // four tile rows per wave (one cout tile): the other two, exposed
+                        static_for<PB, PT>([&](auto pc) { read_bl(pc); });
+                        lgkm_wait<0>();
+                        static_for<PB, PT>([&](auto pc) { make_lo6(pc); });
                     }
-                    if (nt + 2 < NT) read_w8(nt + 2);
                 }
-            }
-#endif
+                const v8i w6 = __builtin_shufflevector(wq[k & 1][0], wq[k & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                static_for<0, PT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    if constexpr (k < NT)
+                        acc[pt][k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, hi6[pt], acc[pt][k], BF6, BF6, 1, w6[6], 0, sb[pt]);
+                    else
+                        acc[pt][k - NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, lo6[pt], acc[pt][k - NT], BF6, BF6, 0, w6[6], 1, sb[pt]);
+                });
+            });
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-#if MPG_STAMPS
-        if ((a.dbg & 8) && a.y != nullptr && s == 0 && lane == 0) {
-            unsigned* o = reinterpret_cast<unsigned*>(a.y) + ((size_t)blockIdx.x * WAVES + wave) * 4;
-            o[0] = sum_dma; o[1] = sum_f16; o[2] = sum_f8; o[3] = sum_bar;
-        }
-#endif
     }
     conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
 }
 
-// F16F8 weight image: per stage (8 consecutive tap slots of the segment's slot stream; fold: 8 channel groups):
-//   [4 k-steps][NT][64 lanes][8 x fp16]  |  [NT][2 halves][64 lanes][16 x fp8 hi]  |  [NT][2 halves][64 lanes][16 x fp8 lo]
-__global__ void pack_weights_f8_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
+// e3m2 code (sign, 3 exponent bits, bias 3, 2 mantissa bits; no infinities) of x, round to nearest even, saturating at 28
+__device__ __forceinline__ int e3m2_encode(float x) {
+    const int s = (__builtin_bit_cast(unsigned, x) >> 31) << 5;
+    const float ax = fabsf(x);
+    if (!(ax < 28.f)) return s | 31;
+    const int e = ax >= 0.25f ? ilogbf(ax) : -2;          // the binade whose step is used; subnormals share the step of [0.25, 0.5)
+    const float step = ldexpf(1.f, e - 2);
+    const float v = rintf(ax / step) * step;              // may reach the next binade
+    if (v == 0.f) return s;
+    const int e2 = ilogbf(v);
+    if (e2 < -2) return s | (int)(v * 16.f);             // subnormal: M * 2^-4
+    return s | (e2 + 3) << 2 | (int)((v * ldexpf(1.f, -e2) - 1.f) * 4.f);
+}
+
+// F16F6 weight image: per stage (8 consecutive tap slots of the segment's slot stream; fold: 8 channel groups):
+//   [4 k-steps][NT][64 lanes][8 x fp16]  |  w_hi6: [NT][2 halves][64 lanes][16 B]  |  w_lo6: same
+// Lane (row r of cout tile nt, half hh) holds the 32 values (k-step j, element e) -> slot 2 j + hh, channel e: the fp16 A
+// fragments of the four k-steps AND, in that order, the K block of 32 of the bf6 instruction.  A bf6 plane keeps the
+// lane's 32 six-bit codes (value i at bits 6 i .. 6 i + 5 of 24 bytes) in bytes 0-15 of half 0 and 0-7 of half 1; bytes
+// 8-11 of half 1 are the scale word {E8M0 of the w_hi block, E8M0 of the w_lo block, 0, 0} (in both planes), 12-15 zero.
+// Block scale: 2^(floor(log2 max|v|) - 3), i.e. the largest code magnitude lies in [8, 16).
+__global__ void pack_weights_f6_kernel(const float* __restrict__ w, int kh, int kw, int cin_total, int c_off,
                                        int cin, int cout, float wscale, const float* __restrict__ cscale,
-                                       int NT, int nchunks, int sc, float s_hi, float s_lo, int fold, int tp,
-                                       char* __restrict__ out) {
-    // fold (direct 1x1 segments): one chunk, the "taps" of a macro-step are 8 consecutive channel groups
+                                       int NT, int sc, int fold, int tp, char* __restrict__ out) {
+    // fold (direct 1x1 segments): the "taps" of a macro-step are 8 consecutive channel groups
     const int T = kh * kw;
-    const long per_stage = (long)NT * 64 * 64;      // one thread per (nt, lane, byte-slot b in 0..63)
-    const long total = (long)nchunks * sc * per_stage;
+    const long total = (long)sc * NT * 64;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int b = idx & 63;
-    const int lane = (idx >> 6) & 63;
-    long rest = idx >> 12;
-    const int nt = rest % NT; rest /= NT;
-    const int st = rest % sc;
-    const int c = rest / sc;                         // (fold / legacy) chunk; 0 in the flat layout
+    const int lane = idx & 63;
+    const int nt = (idx >> 6) % NT;
+    const int st = (int)((idx >> 6) / NT);
     const int r = lane & 31, hh = lane >> 5;
     const int co = nt * 32 + r;
-    const size_t stage_b = (size_t)8 * NT * 1024;
-    char* base = out + ((size_t)c * sc + st) * stage_b;
-    auto weight = [&](int tap, int j) -> float {
-        // flat layout (tp > 0): `tap` is the slot within the stream, slot = group * tp + tap
-        int chn = fold ? tap * 8 + j : c * 8 + j;
-        if (fold) tap = 0;
-        else if (tp > 0) {
-            const int g = tap / tp;
-            tap -= g * tp;
-            chn = g * 8 + j;
-        }
+    char* base = out + (size_t)st * 8 * NT * 1024;
+    auto weight = [&](int slot, int j) -> float {
+        // slot within the stream: fold: channel group `slot`; else group slot / tp, tap slot % tp
+        int tap, chn;
+        if (fold) { tap = 0; chn = slot * 8 + j; }
+        else { const int g = slot / tp; tap = slot - g * tp; chn = g * 8 + j; }
         if (tap >= T || chn >= cin || co >= cout) return 0.f;
         float v = w[((size_t)tap * cin_total + c_off + chn) * cout + co] * wscale;
         if (cscale != nullptr) v *= cscale[co];
         return v;
     };
-    if (b < 32) {
-        // fp16 part: slot b -> k-step j = b >> 3, element e = b & 7: tap = 8 st + 2 j + hh, channel e
-        const int j = b >> 3, e = b & 7;
-        const float v = weight(st * 8 + 2 * j + hh, e);
-        reinterpret_cast<_Float16*>(base)[((size_t)(j * NT + nt) * 64 + lane) * 8 + e] = (_Float16)v;
-    } else {
-        // fp8 parts: byte bb = b - 32 of the lane: tap = 8 st + 4 hh + (bb >> 3), channel bb & 7
-        const int bb = b - 32;
-        const float v = weight(st * 8 + 4 * hh + (bb >> 3), bb & 7);
-        const float lo = v - (float)(_Float16)v;
-        const float lim = 448.f;
-        const int phi = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(v * s_hi, -lim), lim), 0.f, 0, false) & 0xff;
-        const int plo = __builtin_amdgcn_cvt_pk_fp8_f32(fminf(fmaxf(lo * s_lo, -lim), lim), 0.f, 0, false) & 0xff;
-        char* f8 = base + 4 * NT * 1024;
-        // per cout tile: [half of the lane's 32 bytes][lane][16 B] (see lds_read32)
-        const size_t at = (size_t)nt * 2048 + (size_t)(bb >> 4) * 1024 + (size_t)lane * 16 + (bb & 15);
-        f8[at] = (char)phi;
-        f8[(size_t)NT * 2048 + at] = (char)plo;
+    float v[32], lo[32];
+    float mh = 0.f, ml = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        v[i] = weight(st * 8 + 2 * (i >> 3) + hh, i & 7);
+        const _Float16 h = (_Float16)v[i];
+        lo[i] = v[i] - (float)h;
+        mh = fmaxf(mh, fabsf(v[i]));
+        ml = fmaxf(ml, fabsf(lo[i]));
+        reinterpret_cast<_Float16*>(base)[((size_t)((i >> 3) * NT + nt) * 64 + lane) * 8 + (i & 7)] = h;
+    }
+    int eh = mh > 0.f ? ilogbf(mh) - 3 : 0, el = ml > 0.f ? ilogbf(ml) - 3 : 0;
+    eh = eh < -126 ? -126 : eh > 120 ? 120 : eh;
+    el = el < -126 ? -126 : el > 120 ? 120 : el;
+    const int scale_word = (eh + 127) | (el + 127) << 8;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        unsigned d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float inv = ldexpf(1.f, -(pl ? el : eh));
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const unsigned long long c = (unsigned long long)e3m2_encode((pl ? lo[i] : v[i]) * inv) << ((6 * i) & 31);
+            d[(6 * i) >> 5] |= (unsigned)c;
+            if (((6 * i) >> 5) + 1 < 6) d[((6 * i) >> 5) + 1] |= (unsigned)(c >> 32);
+        }
+        d[6] = (unsigned)scale_word;
+        char* p6 = base + 4 * NT * 1024 + (size_t)pl * NT * 2048 + (size_t)nt * 2048 + (size_t)lane * 16;
+        *reinterpret_cast<uint4*>(p6) = make_uint4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<uint4*>(p6 + 1024) = make_uint4(d[4], d[5], d[6], d[7]);
     }
 }
 
@@ -1129,7 +973,7 @@ struct SmallSeg {
 };
 
 struct SmallArgs {
-    int n, h, w, cout, nseg, f8c_in;
+    int n, h, w, cout, nseg;
     int tile_floats;      // floats of the halo tile of the largest segment; the weight table follows it in LDS
     SmallSeg seg[MPG_MAX_SEG];
     const float* bias;
@@ -1138,28 +982,13 @@ struct SmallArgs {
     float leak;
     float* y;
     char* y_g8;
-    char* y_g8c;
 };
 
-__device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, int f8c, float (&v)[8]) {
+__device__ __forceinline__ void g8_load8(const char* src, size_t plane_bytes, float (&v)[8]) {
     const half8 hi = *reinterpret_cast<const half8*>(src);
-    if (!f8c) {
-        const half8 lo = *reinterpret_cast<const half8*>(src + plane_bytes);
+    const half8 lo = *reinterpret_cast<const half8*>(src + plane_bytes);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
-    } else {
-        // plane 1 of the F16F8 flavour: bytes 8..15 hold fp8((v - fp16(v)) * 2^SA_LO)
-        const int2 lo = *reinterpret_cast<const int2*>(src + plane_bytes + 8);
-        const float sc = 1.f / (float)(1 << SA_LO);
-        v[0] = (float)hi[0] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 0) * sc;
-        v[1] = (float)hi[1] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 1) * sc;
-        v[2] = (float)hi[2] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 2) * sc;
-        v[3] = (float)hi[3] + __builtin_amdgcn_cvt_f32_fp8(lo.x, 3) * sc;
-        v[4] = (float)hi[4] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 0) * sc;
-        v[5] = (float)hi[5] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 1) * sc;
-        v[6] = (float)hi[6] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 2) * sc;
-        v[7] = (float)hi[7] + __builtin_amdgcn_cvt_f32_fp8(lo.y, 3) * sc;
-    }
+    for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
 }
 
 // block = 64 x 16 output pixels; a thread owns a COLUMN of four of them (rows 4 yg .. 4 yg + 3 at column lx), so that
@@ -1216,7 +1045,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
             float v[8];
             if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
-                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
+                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, v);
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = 0.f;
@@ -1288,7 +1117,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
             float v[8];
             if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
-                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, a.f8c_in, v);
+                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, v);
             } else {
                 for (int q = 0; q < 8; ++q) v[q] = 0.f;
             }
@@ -1335,20 +1164,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             *reinterpret_cast<half8*>(dst) = hi;
             *reinterpret_cast<half8*>(dst + plane_px * 16) = lo;
         }
-        if (a.y_g8c != nullptr) {
-            half8 hi;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) hi[q] = (_Float16)o[q];
-            char* dst = a.y_g8c + ((size_t)b * 2 * plane_px + pix) * 16;
-            *reinterpret_cast<half8*>(dst) = hi;
-            *reinterpret_cast<int4*>(dst + plane_px * 16) = g8c_plane1(o);
-        }
     }
 }
 
 // fp32 NHWC -> G8
 __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off, int cin,
-                                 int f8c, const float* __restrict__ amax, _Float16* __restrict__ out) {
+                                 const float* __restrict__ amax, _Float16* __restrict__ out) {
     const float scale = amax != nullptr ? mpg::pow2_scale(*amax) : 1.f;
     const int cg_n = (cin + 7) >> 3;
     const size_t plane_px = (size_t)h * w;
@@ -1361,20 +1182,15 @@ __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int 
     const int b = t / cg_n;
     const float* src = x + ((size_t)b * plane_px + px) * c + c_off + cg * 8;
     half8 hi, lo;
-    float vv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float v = (cg * 8 + j < cin) ? src[j] * scale : 0.f;
-        vv[j] = v;
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
     }
     _Float16* dst = out + ((((size_t)b * cg_n + cg) * 2) * plane_px + px) * 8;
     *reinterpret_cast<half8*>(dst) = hi;
-    if (f8c)
-        *reinterpret_cast<int4*>(dst + plane_px * 8) = g8c_plane1(vv);
-    else
-        *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
+    *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
 }
 
 // The same conversion for wide tensors (cin >= 32, 16-byte aligned rows): the kernel above reads 32 bytes per thread at a
@@ -1384,7 +1200,7 @@ __global__ void f32_to_g8_kernel(const float* __restrict__ x, int n, int h, int 
 constexpr int G8T_PX = 32, G8T_CH = 128, G8T_STRIDE = G8T_CH + 4;
 
 __global__ __launch_bounds__(256) void f32_to_g8_tiled_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_off,
-                                                              int cin, int f8c, const float* __restrict__ amax,
+                                                              int cin, const float* __restrict__ amax,
                                                               _Float16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float tile[G8T_PX * G8T_STRIDE];
     const float scale = amax != nullptr ? mpg::pow2_scale(*amax) : 1.f;
@@ -1428,10 +1244,7 @@ __global__ __launch_bounds__(256) void f32_to_g8_tiled_kernel(const float* __res
         }
         _Float16* dst = out + ((((size_t)b * cg_n + (ch0 >> 3) + g) * 2) * plane_px + px0 + p) * 8;
         *reinterpret_cast<half8*>(dst) = hi;
-        if (f8c)
-            *reinterpret_cast<int4*>(dst + plane_px * 8) = g8c_plane1(vv);
-        else
-            *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
+        *reinterpret_cast<half8*>(dst + plane_px * 8) = lo;
     }
 }
 
@@ -1468,7 +1281,7 @@ Shape pipe_shape(int nt, int prec) {
 }
 
 struct SegShape {
-    int cgc, nchunks, sc, np, ni_img, img_bytes, direct, tp;
+    int cgc, nchunks, sc, np, ni_img, img_bytes, direct, tp, pref;
 };
 
 // groups per chunk: two when that removes the half-empty k-step of an odd tap count and the
@@ -1483,6 +1296,7 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
     SegShape s;
     s.direct = 0;
     s.tp = 0;
+    s.pref = 0;
     s.np = np;
     s.cgc = 1;
     if (cg >= 2 && ((kh * kw) & 1)) {
@@ -1498,22 +1312,23 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
     return s;
 }
 
-// ---- MPG_PREC_F16F8 shapes (host mirror of Pipe8<NT>) ----
-bool f8_supported(int nt) { return nt >= 1 && nt <= 4; }
-int f8_waves(int nt) { return nt == 1 ? 4 : 8; }
+// ---- MPG_PREC_F16F6 shapes (host mirror of Pipe6<NT>) ----
+bool f6_supported(int nt) { return nt >= 1 && nt <= 4; }
+int f6_waves(int nt) { return nt == 1 ? 4 : 8; }
 
-SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
+SegShape seg_shape_f6(int kh, int kw, int cin, int nt) {
     // nchunks = channel groups (one LDS halo image each), sc = weight stages of the whole segment
     SegShape s;
     s.direct = 0;
     s.tp = 0;
-    if (kh == 1 && kw == 1 && cin > 8 && nt <= 2) {   // conv_mfma_f8_kernel's direct path: K over channel groups
+    s.pref = 0;
+    if (kh == 1 && kw == 1 && cin > 8 && nt <= 2) {   // conv_mfma_f6_kernel's direct path: K over channel groups
         s.direct = 1; s.cgc = 1; s.np = 0; s.ni_img = 0; s.img_bytes = 0;
         s.nchunks = 1;
         s.sc = ((cin + 7) / 8 + 7) / 8;
         return s;
     }
-    const int waves = f8_waves(nt);
+    const int waves = f6_waves(nt);
     const int px = (16 + kh - 1) * (TW + kw - 1);
     s.np = (px + 63) & ~63;
     s.cgc = 1;
@@ -1527,17 +1342,24 @@ SegShape seg_shape_f8(int kh, int kw, int cin, int nt) {
     const int T = kh * kw;
     s.tp = T >= 16 ? T : T <= 8 ? 8 : T <= 12 ? 12 : 16;
     s.sc = (s.nchunks * s.tp + 7) / 8;
+    // The image of group g is issued in stage ceil((g - 1) tp / 8) (the first stage that no longer touches group g - 2)
+    // and its first slot lies in stage floor(g tp / 8).  The kernel may read stage st + 1's B fragments during stage st
+    // only if every image is then already behind a barrier that followed its DMA wait: two stages between issue and
+    // first use, for every group.
+    s.pref = 1;
+    for (int g = 1; g < s.nchunks; ++g)
+        if ((g * s.tp) / 8 - ((g - 1) * s.tp + 7) / 8 < 2) s.pref = 0;
     return s;
 }
 
 template <int NT>
-hipError_t launch_f8(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
+hipError_t launch_f6(dim3 grid, size_t lds, hipStream_t st, const ConvArgs& a) {
     static int lds_limit[64] = {0};
     if (lds > 48 * 1024) {
-        hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&conv_mfma_f8_kernel<NT>), (int)lds, lds_limit);
+        hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&conv_mfma_f6_kernel<NT>), (int)lds, lds_limit);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((conv_mfma_f8_kernel<NT>), grid, dim3(Pipe8<NT>::WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((conv_mfma_f6_kernel<NT>), grid, dim3(Pipe6<NT>::WAVES * 64), lds, st, a);
     return hipSuccess;
 }
 
@@ -1599,18 +1421,18 @@ extern "C" size_t mpg_g8_bytes(int n, int h, int w, int c) {
 
 extern "C" int mpg_f32_to_g8_scaled(mpg_stream_t stream, const float* x, int n, int h, int w, int c, int c_off, int cin,
                                     int flavour, const float* amax, void* out) {
-    MPG_REQUIRE(flavour == MPG_G8_F16 || flavour == MPG_G8_F8C, "mpg_f32_to_g8: bad flavour %d", flavour);
+    MPG_REQUIRE(flavour == MPG_G8_F16, "mpg_f32_to_g8: bad flavour %d", flavour);
     MPG_REQUIRE(x && out, "mpg_f32_to_g8: null pointer");
     MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && c >= 1 && c_off >= 0 && cin >= 1 && c_off + cin <= c, "mpg_f32_to_g8: bad shape");
     const size_t total = (size_t)n * ((cin + 7) / 8) * h * w;
     if (cin >= 32 && (c % 4) == 0 && (c_off % 4) == 0 && (((uintptr_t)x) & 15) == 0 && n <= 65535) {
         const dim3 grid((unsigned)(((size_t)h * w + G8T_PX - 1) / G8T_PX), (unsigned)((cin + G8T_CH - 1) / G8T_CH), (unsigned)n);
         hipLaunchKernelGGL(f32_to_g8_tiled_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, n, h, w, c, c_off, cin,
-                           flavour == MPG_G8_F8C ? 1 : 0, amax, (_Float16*)out);
+                           amax, (_Float16*)out);
         MPG_LAUNCH_CHECK("f32_to_g8_tiled_kernel");
     }
     hipLaunchKernelGGL(f32_to_g8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n, h,
-                       w, c, c_off, cin, flavour == MPG_G8_F8C ? 1 : 0, amax, (_Float16*)out);
+                       w, c, c_off, cin, amax, (_Float16*)out);
     MPG_LAUNCH_CHECK("f32_to_g8_kernel");
 }
 
@@ -1643,12 +1465,12 @@ extern "C" size_t mpg_conv_pack_size(int kh, int kw, int cin, int cout, int prec
 static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec) {
     if (kh < 1 || kw < 1 || kh > 7 || kw > 7 || cin < 1 || cout < 1 || cout > 128) return 0;
     const int nt = (cout + 31) / 32;
-    if (prec == MPG_PREC_F16F8) {
-        if (!f8_supported(nt)) return 0;
-        const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
+    if (prec == MPG_PREC_F16F6) {
+        if (!f6_supported(nt)) return 0;
+        const SegShape ss = seg_shape_f6(kh, kw, cin, nt);
         // a segment whose tables + two images + ring cannot fit the 160 KiB of LDS is "not available at this
         // precision" (callers then pack for MPG_PREC_F16X3), e.g. 7x7 with four cout tiles
-        const size_t tabs = ss.direct ? TAPOFF_BYTES : 2 * ((((size_t)ss.sc * 8 * 4 + 1023) / 1024) * 1024);
+        const size_t tabs = ss.direct ? TAPOFF_BYTES : (((size_t)ss.sc * 8 * 4 + 1023) / 1024) * 1024;
         if ((tabs < (size_t)TAPOFF_BYTES ? (size_t)TAPOFF_BYTES : tabs) + 2 * (size_t)ss.img_bytes + (size_t)3 * 8 * nt * 1024 > 160 * 1024)
             return 0;
         return (size_t)ss.sc * 8 * nt * 1024;
@@ -1662,9 +1484,9 @@ static size_t pack_base_bytes(int kh, int kw, int cin, int cout, int prec) {
 
 extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int kw, int w_cin_total,
                                      int w_c_off, int cin, int cout, float wscale, const float* cout_scale, int prec,
-                                     int w_exp, void* out, size_t out_bytes) {
+                                     void* out, size_t out_bytes) {
     MPG_REQUIRE(w_hwio && out, "mpg_conv_pack_weights: null pointer");
-    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3 || prec == MPG_PREC_F16F8,
+    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3 || prec == MPG_PREC_F16F6,
                 "mpg_conv_pack_weights: bad prec %d", prec);
     MPG_REQUIRE(kh >= 1 && kh <= 7 && kw >= 1 && kw <= 7, "mpg_conv_pack_weights: kernel %dx%d unsupported", kh, kw);
     MPG_REQUIRE(cin >= 1 && w_c_off >= 0 && w_c_off + cin <= w_cin_total, "mpg_conv_pack_weights: channel range");
@@ -1673,18 +1495,17 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
     MPG_REQUIRE(need > 0, "mpg_conv_pack_weights: %dx%d %d->%d not available at prec %d", kh, kw, cin, cout, prec);
     MPG_REQUIRE(out_bytes >= need, "mpg_conv_pack_weights: out buffer %zu < %zu", out_bytes, need);
     const int nt = (cout + 31) / 32;
-    if (prec == MPG_PREC_F16F8) {
-        MPG_REQUIRE(w_exp >= -100 && w_exp <= 100, "mpg_conv_pack_weights: w_exp %d out of range", w_exp);
-        const SegShape ss = seg_shape_f8(kh, kw, cin, nt);
-        const long total = (long)ss.sc * nt * 64 * 64;
-        hipLaunchKernelGGL(pack_weights_f8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                           w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, 1, ss.sc,
-                           ldexpf(1.f, w_exp), ldexpf(1.f, w_exp + 11), ss.direct, ss.tp, (char*)out);
+    if (prec == MPG_PREC_F16F6) {
+        const SegShape ss = seg_shape_f6(kh, kw, cin, nt);
+        const long total = (long)ss.sc * nt * 64;
+        hipLaunchKernelGGL(pack_weights_f6_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                           w_hwio, kh, kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale, nt, ss.sc, ss.direct, ss.tp,
+                           (char*)out);
         if (small_layer(cin, cout))
             hipLaunchKernelGGL(pack_small_kernel, dim3((kh * kw * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_hwio,
                                kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
                                (float*)((char*)out + pack_base_bytes(kh, kw, cin, cout, prec)));
-        MPG_LAUNCH_CHECK("pack_weights_f8_kernel");
+        MPG_LAUNCH_CHECK("pack_weights_f6_kernel");
     }
     const Shape ps = pipe_shape(nt, prec);
     const SegShape ss = seg_shape(kh, kw, cin, nt, prec);
@@ -1712,8 +1533,8 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(d->n >= 1 && d->h >= 1 && d->w >= 1, "mpg_conv2d_fused: bad shape %d x %d x %d", d->n, d->h, d->w);
     MPG_REQUIRE(d->cout >= 1 && d->cout <= 128, "mpg_conv2d_fused: cout %d not in 1..128", d->cout);
     MPG_REQUIRE(d->nseg >= 1 && d->nseg <= MPG_MAX_SEG, "mpg_conv2d_fused: nseg %d", d->nseg);
-    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr || d->y_g8c != nullptr, "mpg_conv2d_fused: no output requested");
-    MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3 || d->prec == MPG_PREC_F16F8,
+    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr, "mpg_conv2d_fused: no output requested");
+    MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3 || d->prec == MPG_PREC_F16F6,
                 "mpg_conv2d_fused: bad prec %d", d->prec);
     MPG_REQUIRE(d->act >= MPG_ACT_NONE && d->act <= MPG_ACT_TANH, "mpg_conv2d_fused: bad act %d", d->act);
     {   // small-channel layers: conv_small_kernel
@@ -1722,7 +1543,6 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         if (small) {
             SmallArgs sa;
             sa.n = d->n; sa.h = d->h; sa.w = d->w; sa.cout = d->cout; sa.nseg = d->nseg;
-            sa.f8c_in = d->prec == MPG_PREC_F16F8 ? 1 : 0;
             for (int s = 0; s < d->nseg; ++s) {
                 const mpg_conv_seg& g = d->seg[s];
                 MPG_REQUIRE(g.x && g.wpack, "mpg_conv2d_fused: segment %d null pointer", s);
@@ -1740,8 +1560,8 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
             }
             for (int s = d->nseg; s < MPG_MAX_SEG; ++s) sa.seg[s] = sa.seg[0];
             sa.bias = d->bias; sa.in_amax = d->in_amax; sa.act = d->act; sa.leak = d->leak;
-            sa.y = d->y; sa.y_g8 = (char*)d->y_g8; sa.y_g8c = (char*)d->y_g8c;
-            MPG_REQUIRE((((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0, "mpg_conv2d_fused: misaligned output");
+            sa.y = d->y; sa.y_g8 = (char*)d->y_g8;
+            MPG_REQUIRE((((uintptr_t)d->y_g8) & 15) == 0, "mpg_conv2d_fused: misaligned output");
             const size_t total = (size_t)d->n * d->h * d->w;
             (void)total;
             const dim3 sg((unsigned)((d->w + SM_TW - 1) / SM_TW), (unsigned)((d->h + SM_TH - 1) / SM_TH), (unsigned)d->n);
@@ -1774,13 +1594,13 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         }
     }
     const int nt = (d->cout + 31) / 32;
-    const bool f8 = d->prec == MPG_PREC_F16F8;
-    if (f8 && !f8_supported(nt)) {
-        mpg::set_error("mpg_conv2d_fused: MPG_PREC_F16F8 not available for cout %d", d->cout);
+    const bool f8 = d->prec == MPG_PREC_F16F6;
+    if (f8 && !f6_supported(nt)) {
+        mpg::set_error("mpg_conv2d_fused: MPG_PREC_F16F6 not available for cout %d", d->cout);
         return MPG_ERR_UNSUPPORTED;
     }
     Shape ps = pipe_shape(nt, f8 ? MPG_PREC_F16X3 : d->prec);
-    if (f8) { ps.th = 16; ps.pt = 16 / f8_waves(nt); }
+    if (f8) { ps.th = 16; ps.pt = 16 / f6_waves(nt); }
     const int npl = d->prec == MPG_PREC_F16X3 ? 2 : 1;
 
     ConvArgs a;
@@ -1796,7 +1616,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         MPG_REQUIRE((d->h % (1 << g.up_log2)) == 0 && (d->w % (1 << g.up_log2)) == 0,
                     "mpg_conv2d_fused: segment %d: %dx%d not divisible by upsample %d", s, d->h, d->w, 1 << g.up_log2);
         MPG_REQUIRE((((uintptr_t)g.x) & 15) == 0 && (((uintptr_t)g.wpack) & 15) == 0, "mpg_conv2d_fused: segment %d misaligned", s);
-        const SegShape ss = f8 ? seg_shape_f8(g.kh, g.kw, g.cin, nt) : seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
+        const SegShape ss = f8 ? seg_shape_f6(g.kh, g.kw, g.cin, nt) : seg_shape(g.kh, g.kw, g.cin, nt, d->prec);
         MPG_REQUIRE(f8 || ss.sc * ps.ks * 2 <= TAPOFF_BYTES / 4, "mpg_conv2d_fused: segment %d tap table too large", s);
         if (f8 && !ss.direct) max_slots = ss.sc * 8 > max_slots ? ss.sc * 8 : max_slots;
         SegArgs& o = a.seg[s];
@@ -1812,12 +1632,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
         o.tp = ss.tp;
         MPG_REQUIRE(!ss.direct || (size_t)(d->h >> g.up_log2) * (d->w >> g.up_log2) * 16 * 16 < ((size_t)1 << 31),
                     "mpg_conv2d_fused: segment %d: %dx%d too large for the 1x1 path (32-bit group offsets)", s, d->h, d->w);
-        o.sw_hi = o.sw_lo = 0;
-        if (f8) {
-            MPG_REQUIRE(g.w_exp >= -100 && g.w_exp <= 100, "mpg_conv2d_fused: segment %d w_exp %d", s, g.w_exp);
-            o.sw_hi = (127 - g.w_exp) * 0x01010101;
-            o.sw_lo = (127 - g.w_exp - 11) * 0x01010101;
-        }
+        o.pref = ss.pref;
         max_img = ss.img_bytes > max_img ? ss.img_bytes : max_img;
     }
     for (int s = d->nseg; s < MPG_MAX_SEG; ++s) a.seg[s] = a.seg[0];
@@ -1826,8 +1641,7 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     MPG_REQUIRE(!d->post_add || d->post_add_coff + d->cout <= d->post_add_stride, "mpg_conv2d_fused: post_add channel range");
     a.y = d->y;
     a.y_g8 = (char*)d->y_g8;
-    a.y_g8c = (char*)d->y_g8c;
-    MPG_REQUIRE((((uintptr_t)d->y) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0 && (((uintptr_t)d->y_g8c) & 15) == 0,
+    MPG_REQUIRE((((uintptr_t)d->y) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0,
                 "mpg_conv2d_fused: misaligned output");
     a.zeros = zero_buffer();
     MPG_REQUIRE(a.zeros != nullptr, "mpg_conv2d_fused: could not allocate the zero page");
@@ -1837,10 +1651,10 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     a.dbg = d->reserved;
     const long nblk = (long)d->n * a.tiles_x * a.tiles_y;
     MPG_REQUIRE(nblk < (1L << 31), "mpg_conv2d_fused: grid too large");
-    const int waves = f8 ? f8_waves(nt) : 4;
+    const int waves = f8 ? f6_waves(nt) : 4;
     const size_t ring = f8 ? (size_t)3 * 8 * nt * 1024 : (size_t)ps.r * ps.ks * nt * 1024 * npl;
-    // F16F8: two tap-offset tables (slot order, fp16 k-step order) of max_slots entries, 1 KiB granules
-    a.tap_bytes = f8 ? 2 * (((max_slots * 4 + 1023) / 1024) * 1024) : TAPOFF_BYTES;
+    // F16F6: the tap-offset table ([stage][half][k-step]) of max_slots entries, 1 KiB granules
+    a.tap_bytes = f8 ? ((max_slots * 4 + 1023) / 1024) * 1024 : TAPOFF_BYTES;
     if (a.tap_bytes < TAPOFF_BYTES) a.tap_bytes = TAPOFF_BYTES;
     const size_t lds_loop = (size_t)a.tap_bytes + 2 * (size_t)max_img + ring;
     const size_t lds_epi = TAPOFF_BYTES + (size_t)waves * 32 * (nt * 32 + 4) * sizeof(float);
@@ -1850,10 +1664,10 @@ extern "C" int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* d) {
     hipError_t le;
     if (f8) {
         switch (nt) {
-            case 1: le = launch_f8<1>(grid, lds, (hipStream_t)stream, a); break;
-            case 2: le = launch_f8<2>(grid, lds, (hipStream_t)stream, a); break;
-            case 3: le = launch_f8<3>(grid, lds, (hipStream_t)stream, a); break;
-            default: le = launch_f8<4>(grid, lds, (hipStream_t)stream, a); break;
+            case 1: le = launch_f6<1>(grid, lds, (hipStream_t)stream, a); break;
+            case 2: le = launch_f6<2>(grid, lds, (hipStream_t)stream, a); break;
+            case 3: le = launch_f6<3>(grid, lds, (hipStream_t)stream, a); break;
+            default: le = launch_f6<4>(grid, lds, (hipStream_t)stream, a); break;
         }
     } else if (d->prec == MPG_PREC_F16X3)
         le = launch_nt<3>(nt, grid, lds, (hipStream_t)stream, a);

@@ -5,22 +5,21 @@ enqueues hand-written HIP kernels from libmpgan_hip.so on torch's current
 stream.  Tensors are NHWC float32 on the GPU.
 """
 import ctypes
-import math
 
 import torch
 
 from . import _lib
-from ._lib import G8_F16, G8_F8C, PREC_F16F8, PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
+from ._lib import G8_F16, PREC_F16F6, PREC_F16X1, PREC_F16X3  # noqa: F401  (re-exported)
 
 DEFAULT_PREC = PREC_F16X3     # kernel-level default (weight packing, generic sessions, training)
 # what the inference drivers and multipass.Generator run unless told otherwise (`prec` parameter): held to
 # 5e-4 relative L2 of the oracle at the full C2 / C4 sizes by tests/test_fullsize_gpu.py (north_star: 1e-3)
-INFERENCE_PREC = PREC_F16F8
+INFERENCE_PREC = PREC_F16F6
 
 
 def parse_prec(v):
-    """`prec` parameter of the GAN/ drivers: 2 / "f16f8" (default), 3 / "f16x3" (fp32-grade), 1 / "f16x1" """
-    names = {"f16f8": PREC_F16F8, "f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "fp32": PREC_F16X3}
+    """`prec` parameter of the GAN/ drivers: 2 / "f16f6" (default), 3 / "f16x3" (fp32-grade), 1 / "f16x1" """
+    names = {"f16f6": PREC_F16F6, "f16x3": PREC_F16X3, "f16x1": PREC_F16X1, "fp32": PREC_F16X3}
     s = str(v).strip().lower()
     if s in names:
         return names[s]
@@ -28,8 +27,8 @@ def parse_prec(v):
         p = int(s)
     except ValueError:
         p = -1
-    if p not in (PREC_F16X1, PREC_F16F8, PREC_F16X3):
-        raise _lib.MpgError("prec %r: expected 1 (f16x1), 2 (f16f8) or 3 (f16x3)" % (v,))
+    if p not in (PREC_F16X1, PREC_F16F6, PREC_F16X3):
+        raise _lib.MpgError("prec %r: expected 1 (f16x1), 2 (f16f6) or 3 (f16x3)" % (v,))
     return p
 
 
@@ -70,17 +69,17 @@ class G8(object):
 
 
 def flavour_for(prec):
-    """the G8 flavour a launch of precision `prec` reads"""
-    return G8_F8C if prec == PREC_F16F8 else G8_F16
+    """the G8 flavour a launch of precision `prec` reads: every precision reads (hi16, lo16) since round 3"""
+    return G8_F16
 
 
-def f8_available(cout, segments=()):
-    """MPG_PREC_F16F8 is built for every output width of the fused convolution (1..128); a segment (kh, kw, cin)
+def f6_available(cout, segments=()):
+    """MPG_PREC_F16F6 is built for every output width of the fused convolution (1..128); a segment (kh, kw, cin)
     whose LDS images do not fit at that width (7x7 with four cout tiles) answers 0 to the pack-size query"""
     if not 1 <= cout <= 128:
         return False
     lib = _lib.load()
-    return all(lib.mpg_conv_pack_size(kh, kw, cin, cout, PREC_F16F8) > 0 for (kh, kw, cin) in segments)
+    return all(lib.mpg_conv_pack_size(kh, kw, cin, cout, PREC_F16F6) > 0 for (kh, kw, cin) in segments)
 
 
 def absmax(x):
@@ -120,10 +119,10 @@ def from_g8(g):
 class PackedWeights(object):
     """Weights of one conv segment in MFMA fragment order (mpg_conv_pack_weights)."""
 
-    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec", "w_exp")
+    __slots__ = ("buf", "kh", "kw", "cin", "cout", "prec")
 
-    def __init__(self, buf, kh, kw, cin, cout, prec, w_exp=0):
-        self.buf, self.kh, self.kw, self.cin, self.cout, self.prec, self.w_exp = buf, kh, kw, cin, cout, prec, w_exp
+    def __init__(self, buf, kh, kw, cin, cout, prec):
+        self.buf, self.kh, self.kw, self.cin, self.cout, self.prec = buf, kh, kw, cin, cout, prec
 
 
 def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, prec=DEFAULT_PREC):
@@ -139,18 +138,10 @@ def pack_conv_weights(w_hwio, wscale=1.0, cout_scale=None, c_off=0, cin=None, pr
         raise _lib.MpgError("mpg_conv_pack_size: unsupported conv %dx%d %d->%d" % (kh, kw, cin, cout))
     buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     cs = _dev(cout_scale, "cout_scale") if cout_scale is not None else None
-    w_exp = 0
-    if prec == PREC_F16F8:
-        # exponent of the fp8 weight planes: max |w_eff| * 2^w_exp <= 224 (half the e4m3 range)
-        wm = w[:, :, c_off:c_off + cin, :].abs().amax(dim=(0, 1, 2))
-        if cs is not None:
-            wm = wm * cs.abs()
-        top = float(wm.max().item()) * abs(float(wscale))
-        w_exp = 0 if top <= 0 else max(-60, min(60, int(math.floor(math.log2(224.0 / top)))))
     rc = lib.mpg_conv_pack_weights(_stream(), _ptr(w), kh, kw, cin_total, c_off, cin, cout, float(wscale), _ptr(cs),
-                                   prec, w_exp, _ptr(buf), nbytes)
+                                   prec, _ptr(buf), nbytes)
     _lib.check(rc, "mpg_conv_pack_weights")
-    return PackedWeights(buf, kh, kw, cin, cout, prec, w_exp)
+    return PackedWeights(buf, kh, kw, cin, cout, prec)
 
 
 class Segment(object):
@@ -170,11 +161,11 @@ class Segment(object):
 
 
 def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=False, pn_eps=1e-8,
-                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, want_g8c=False, reserved=0,
+                 post_add=None, post_add_coff=0, out=None, want_f32=True, want_g8=False, reserved=0,
                  in_amax=None):
     """y = post(act(sum_s conv_SAME(up_s(x_s), W_s) + bias)) [+ post_add]; see include/mpgan.h.
-    Returns the requested outputs in the order (fp32 NHWC, G8, G8 in the F16F8 flavour): a single
-    object when one is requested, else a tuple."""
+    Returns the requested outputs in the order (fp32 NHWC, G8): a single object when one is requested,
+    else a tuple."""
     lib = _lib.load()
     if not 1 <= len(segments) <= _lib.MAX_SEG:
         raise _lib.MpgError("conv2d_fused: %d segments (1..%d supported)" % (len(segments), _lib.MAX_SEG))
@@ -200,7 +191,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         g = d.seg[i]
         g.x, g.wpack = g8.buf.data_ptr(), pk.buf.data_ptr()
         g.cin, g.cgroups, g.g_off = pk.cin, g8.groups, s.g_off
-        g.kh, g.kw, g.up_log2, g.w_exp = pk.kh, pk.kw, s.up_log2, pk.w_exp
+        g.kh, g.kw, g.up_log2 = pk.kh, pk.kw, s.up_log2
         g.pad_hi = s.pad_hi
     if bias is not None:
         b = _dev(bias, "bias")
@@ -214,7 +205,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
         if pa.dim() != 4 or tuple(pa.shape[:3]) != (n, h, w) or post_add_coff + p0.cout > pa.shape[3]:
             raise _lib.MpgError("conv2d_fused: post_add %s does not match output" % (tuple(pa.shape),))
         d.post_add, d.post_add_stride, d.post_add_coff = pa.data_ptr(), pa.shape[3], post_add_coff
-    y = y8 = y8c = None
+    y = y8 = None
     if out is not None:
         want_f32 = True
     if want_f32:
@@ -228,10 +219,7 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
     if want_g8:
         y8 = G8.empty(n, h, w, p0.cout, dev, G8_F16)
         d.y_g8 = y8.buf.data_ptr()
-    if want_g8c:
-        y8c = G8.empty(n, h, w, p0.cout, dev, G8_F8C)
-        d.y_g8c = y8c.buf.data_ptr()
-    outs = [o for o in (y, y8, y8c) if o is not None]
+    outs = [o for o in (y, y8) if o is not None]
     if not outs:
         raise _lib.MpgError("conv2d_fused: no output requested")
     d.prec, d.reserved = p0.prec, reserved
@@ -317,13 +305,13 @@ def conv2d_transpose(x, w_hwoi, stride=(1, 1), wscale=1.0, bias=None, act=None, 
     if prec is not None and sh == sw and sh in (1, 2):
         if sh == 1 and kh <= 7 and kw <= 7 and cout <= 128:
             v = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()
-            p = prec if f8_available(cout, [(kh, kw, cin)]) or prec != PREC_F16F8 else PREC_F16X3
+            p = prec if f6_available(cout, [(kh, kw, cin)]) or prec != PREC_F16F6 else PREC_F16X3
             seg = Segment(x, pack_conv_weights(v, wscale=wscale, prec=p), pad_hi=1)
             return conv2d_fused([seg], (h, wd), bias=b, act=act, leak=leak)
         if sh == 2 and 4 * cout <= 128:
             v = subpixel_filter(w, 2)
             if v.shape[0] <= 7 and v.shape[1] <= 7:
-                p = prec if f8_available(4 * cout, [(v.shape[0], v.shape[1], cin)]) or prec != PREC_F16F8 else PREC_F16X3
+                p = prec if f6_available(4 * cout, [(v.shape[0], v.shape[1], cin)]) or prec != PREC_F16F6 else PREC_F16X3
                 seg = Segment(x, pack_conv_weights(v, wscale=wscale, prec=p))
                 z = conv2d_fused([seg], (h, wd), bias=b.repeat(4) if b is not None else None, act=act, leak=leak)
                 return depth_to_space(z, 2)

@@ -257,8 +257,7 @@ class Session(object):
                 need_f32.add(fn.info["post_add_id"])
         for n, fn in fused_steps:
             fn.emit["g8"] = (n.id, ops.G8_F16) in need_g8
-            fn.emit["g8c"] = (n.id, ops.G8_F8C) in need_g8
-            fn.emit["f32"] = n.id in need_f32 or not (fn.emit["g8"] or fn.emit["g8c"])
+            fn.emit["f32"] = n.id in need_f32 or not fn.emit["g8"]
         # variables, placeholders and the fetch stay alive; everything else dies after its last reader
         plan.free_after = [[] for _ in plan.steps]
         keep = set(n.id for n, _ in plan.steps if n.op in ("variable", "placeholder"))
@@ -341,11 +340,11 @@ class Session(object):
         for pat, pr in self.prec_map:
             if pat in lead:
                 prec = pr
-        if prec == ops.PREC_F16F8 and not ops.f8_available(
+        if prec == ops.PREC_F16F6 and not ops.f6_available(
                 cout, [(sg[3].conv.inputs[1].shape[0], sg[3].conv.inputs[1].shape[1], sg[5]) for sg in segs]):
-            prec = ops.PREC_F16X3      # shapes the F16F8 kernels do not cover keep the fp16 split
+            prec = ops.PREC_F16X3      # shapes the F16F6 kernels do not cover keep the fp16 split
 
-        emit = {"f32": True, "g8": False, "g8c": False}
+        emit = {"f32": True, "g8": False}
 
         def run(env, segs=segs, terms=terms, prec=prec):
             seg_objs = []
@@ -357,14 +356,13 @@ class Session(object):
             pa = self._f32(env, post_add) if post_add is not None else None
             if self.tap is not None and self.tap in lead:
                 self.tapped = dict(segments=seg_objs, out_hw=out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn,
-                                   pn_eps=pn_eps, post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"],
-                                   want_g8c=emit["g8c"])
+                                   pn_eps=pn_eps, post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"])
             timed = self.tap is not None and self.tap_events is not None and self.tap in lead
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
-                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"], want_g8c=emit["g8c"])
+                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"])
             if timed:
                 ev[1].record()
                 self.tap_events.append(ev)
@@ -374,8 +372,6 @@ class Session(object):
                 out["f32"] = res.pop(0)
             if emit["g8"]:
                 out["g8"][ops.G8_F16] = res.pop(0)
-            if emit["g8c"]:
-                out["g8"][ops.G8_F8C] = res.pop(0)
             return out
 
         run.emit = emit

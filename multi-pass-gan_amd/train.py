@@ -452,7 +452,7 @@ class TrainSession(object):
         self.vars = variables
         if prec not in (ops.PREC_F16X3, ops.PREC_F16X1):
             # the weight-gradient kernel contracts over pixels with fp16 hi/lo operands only
-            raise _lib.MpgError("training runs MPG_PREC_F16X3 (or F16X1); MPG_PREC_F16F8 is an inference mode")
+            raise _lib.MpgError("training runs MPG_PREC_F16X3 (or F16X1); MPG_PREC_F16F6 is an inference mode")
         self.prec = prec
         self.bn_decay = bn_decay
         self.device = torch.device(device)

@@ -32,9 +32,9 @@ def test_struct_layout_matches_header(mpg):
     import ctypes
     from mpgan_amd import _lib
     assert ctypes.sizeof(_lib.ConvSeg) == 48
-    assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 48 + 72 + 8
-    assert _lib.ConvDesc.y_g8.offset == 264 and _lib.ConvDesc.y_g8c.offset == 272 and _lib.ConvDesc.reserved.offset == 284
-    assert _lib.ConvDesc.in_amax.offset == 288
+    assert _lib.ConvDesc.seg.offset == 24 and ctypes.sizeof(_lib.ConvDesc) == 24 + 4 * 48 + 64 + 8
+    assert _lib.ConvDesc.y_g8.offset == 264 and _lib.ConvDesc.prec.offset == 272 and _lib.ConvDesc.reserved.offset == 276
+    assert _lib.ConvDesc.in_amax.offset == 280
 
 
 def test_compute_refuses_without_gpu(mpg):
@@ -113,19 +113,18 @@ def test_fusion_plan(mpg):
     launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] == "conv2d_fused"]
     assert [e["cout"] for e in launches] == [2, 8, 128, 128, 32, 8, 2, 1]
     # activations between fused launches travel as G8 only; the fetched tensor is fp32
-    assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True, "g8c": False}] * 7
-    assert launches[-1]["emit"] == {"f32": True, "g8": False, "g8c": False}
-    # F16F8: every launch of this net has 1 or 4 cout tiles, so all of it runs in that mode
-    gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)   # default: F16F8
+    assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True}] * 7
+    assert launches[-1]["emit"] == {"f32": True, "g8": False}
+    # F16F6: every launch of this net has 1 or 4 cout tiles, so all of it runs in that mode
+    gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)   # default: F16F6
     lf = [e for e in gf.sess.plan_summary(gf.sampler) if e["kind"] == "conv2d_fused"]
-    assert all(e["prec"] == 2 for e in lf) and all(e["emit"]["g8c"] and not e["emit"]["g8"] for e in lf[:-1])
-    # a per-launch precision map mixes modes; a tensor feeding both kinds of launch is emitted in both G8 flavours
+    assert all(e["prec"] == 2 for e in lf) and all(e["emit"]["g8"] and not e["emit"]["f32"] for e in lf[:-1])
+    # a per-launch precision map mixes modes; every mode reads the same G8 tensor
     g8x = MP.Generator("growing_gen", dict(tile_low=8, up_res=8, channels=4, first_gen=True, filter_size=3, start_fms=256,
                                            max_fms=256, add_adj=True, first_nn_arch=True), None, prec=2,
                        prec_map=[("genBlock4/g_cA_second", 3)])
     l8 = [e for e in g8x.sess.plan_summary(g8x.sampler) if e["kind"] == "conv2d_fused"]
     assert set(e["prec"] for e in l8) == {2, 3}
-    assert any(e["emit"]["g8"] and e["emit"]["g8c"] for e in l8)
     assert [len(e["segments"]) for e in launches] == [1, 2, 1, 2, 1, 2, 1, 2]
     assert launches[0]["segments"][0]["up_log2"] == 2 and launches[1]["segments"][1]["up_log2"] == 2
     assert all(e["act"] == "relu" for e in launches)

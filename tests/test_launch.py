@@ -42,8 +42,9 @@ def test_rank_env_and_json_picker(mpg):
 @pytest.mark.timeout(600)
 def test_bench_parent_launches_children_without_touching_the_gpu():
     """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns two ranks.  Without a GPU the ranks stop
-    with "needs an MI355X"; the parent retries once in the exchange-free mode, then reports the failure (rc != 0,
-    no JSON line) and does not hang.
+    with "needs an MI355X"; the parent then runs the exchange-free partition once with fresh ranks (for the record
+    only) and reports the FAILED benchmark: rc != 0 and a JSON line whose `value` is null -- a failed sharded run must
+    never look like a pass -- and it does not hang.
     The parent path does not even import torch (checked below), so it cannot have initialised the runtime."""
     chk = ("import sys; sys.path.insert(0, %r); import bench, mpgan_amd.launch; "
            "assert 'torch' not in sys.modules, 'parent path imports torch'" % ROOT)
@@ -57,5 +58,7 @@ def test_bench_parent_launches_children_without_touching_the_gpu():
     # the sharded job fails, the parent then tries the exchange-free partition (whole volumes per rank), which fails too
     # (a rank may be stopped by the launcher before it has printed, once its sibling has failed: 2..4 messages)
     assert 2 <= p.stderr.count("needs an MI355X") <= 4, p.stderr[-2000:]
-    assert "measuring whole volumes per rank instead" in p.stderr
-    assert "{" not in p.stdout
+    assert "measuring whole volumes per rank for the record" in p.stderr
+    import json
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 2 and "sharded_error" in line and "value_replicas" not in line
