@@ -89,10 +89,7 @@ def train_main():
     toSim = fromSim if toSim == -1 else toSim
     randSeed = int(P["randSeed"])
     kt, kt_l = float(P["lambda_t"]), float(P["lambda_t_l2"])
-    useTempoD = kt > 1e-6                                              # 4x.py:147-152
-    if kt_l > 1e-6:
-        print("ERROR: the l2 temporal loss (lambda_t_l2) is not built; use lambda_t")
-        exit(1)
+    useTempoD, useTempoL2 = kt > 1e-6, kt_l > 1e-6                     # 4x.py:147-152
     channelLayout_low, mfl, mfh = 'd', ["density"], ["density"]
     if useVelocities:
         channelLayout_low += ',vx,vy,vz'
@@ -164,7 +161,8 @@ def train_main():
                         beta1=float(P["adam_beta1"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
                         lambda2_l=tuple(float(P["lambda2_l%d" % i]) for i in (1, 2, 3, 4)),
                         weight_dld=float(P["weight_dld"]), bn_decay=float(P["bnDecay"]), seed=randSeed,
-                        use_tempo=useTempoD, lambda_t=kt, adv_flag=int(P["adv_flag"]) > 0, clamping=int(P["clamping"]) > 0)
+                        use_tempo=useTempoD, lambda_t=kt, adv_flag=int(P["adv_flag"]) > 0, clamping=int(P["clamping"]) > 0,
+                        lambda_t_l2=kt_l)
     if load_model_test >= 0:
         params = checkpoint.load(checkpoint.model_path(basePath, load_model_test, load_model_no))
         with torch.no_grad():
@@ -222,7 +220,7 @@ def train_main():
         for _ in range(genRuns):
             bx, by = getinput()
             trainer.k, trainer.k2 = k_f * trainer.k, k2_f * trainer.k2   # :1342-1343
-            if useTempoD:
+            if useTempoD or useTempoL2:                                  # :1352-1363
                 tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
                 L = trainer.gen_step_tempo(bx, by, *tempo)
             else:

@@ -153,8 +153,11 @@ if (upsampling_mode, upsampled_data) not in ((2, 0), (1, 1), (3, 1)) or int(P["d
 later_net = upsampling_mode != 2
 if int(P["useVorticities"]) or int(P["useFlags"]) or int(P["useK_Eps_Turb"]) or int(P["premadeTiles"]):
     fail("vorticity / flag / k-eps inputs and premade tiles are not supported")
-if int(P["batchNorm"]) or int(P["usePixelShuffle"]) or int(P["use_mb_stddev"]) or int(P["gDrop"]) or int(P["useVelInTDisc"]):
-    fail("batchNorm / usePixelShuffle / use_mb_stddev / gDrop / useVelInTDisc are 0 in the reference runs and not built")
+if int(P["usePixelShuffle"]) or int(P["gDrop"]) or int(P["useVelInTDisc"]):
+    fail("usePixelShuffle / gDrop / useVelInTDisc are 0 in the reference runs and not built")
+if (int(P["batchNorm"]) or int(P["use_mb_stddev"])) and int(P["use_wgan_gp"]):
+    fail("batchNorm / use_mb_stddev (8x.py:85,149) train with use_wgan_gp 0 (LSGAN or sigmoid cross entropy): the gradient "
+         "penalty would need second derivatives of the batch statistics, which are not built")
 upRes = int(P["upRes"])
 if upRes != 8:
     fail("the growing networks are built for upRes 8")
@@ -254,14 +257,14 @@ cfg = Cfg8x(tileSizeLow=tileSizeLow, upRes=upRes, n_inputChannels=n_inputChannel
             upsampleMode=int(P["upsampleMode"]), filterSize=int(P["filterSize"]), start_fms=int(P["startFms"]),
             max_fms=int(P["maxFms"]), first_nn_arch=int(P["firstNNArch"]) > 0, use_res_net=int(P["use_res_net"]) > 0,
             pixel_norm=int(P["pixelNorm"]) > 0, addBicubicUpsample=int(P["addBicubicUpsample"]) > 0,
-            bn_decay=float(P["bnDecay"]))
+            use_mb_stddev=int(P["use_mb_stddev"]) > 0, bn_decay=float(P["bnDecay"]))
 learning_rate = float(P["learningRate"])
 trainer = Trainer8x(cfg, device=device, learning_rate=learning_rate, beta1=float(P["adam_beta1"]),
                     beta2=float(P["adam_beta2"]), lambda_l1=float(P["lambda"]), lambda2=float(P["lambda2"]),
                     weight_dld=float(P["weight_dld"]), use_wgan_gp=int(P["use_wgan_gp"]) > 0,
                     use_LSGAN=int(P["use_LSGAN"]) > 0, seed=randSeed, use_tempo=useTempoD, lambda_t=kt,
                     adv_flag=int(P["adv_flag"]) > 0, loss_scaling=int(P["lossScaling"]) > 0,
-                    adv_mode=int(P["adv_mode"]))
+                    adv_mode=int(P["adv_mode"]), batch_norm=int(P["batchNorm"]) > 0)
 if int(P["load_model_test"]) >= 0:
     params = checkpoint.load(checkpoint.model_path(basePath, int(P["load_model_test"]), int(P["load_model_no"])))
     with torch.no_grad():

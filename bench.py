@@ -58,6 +58,13 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="both", choices=("both", "sharded", "replicas"),
                     help="N > 1: `sharded` = slices of every volume over the ranks + all-gather between the passes "
                          "(north_star; this is `value`), `replicas` = whole volumes per rank, no exchange; both = time both")
+    ap.add_argument("--exchange", default="all_gather", choices=("all_gather", "all_to_all"),
+                    help="N > 1, sharded mode: how a pass's slabs reach the next pass.  all_gather (north_star): the whole "
+                         "volume to every rank; all_to_all: only the blocks each rank's planes need (1/N of the bytes).  "
+                         "With --mode both the other one is timed too and reported as value_<exchange>")
+    ap.add_argument("--workload", default="c2", choices=("c2", "c4"),
+                    help="c2 (default, the headline): BASELINE configs[1]; c4: BASELINE configs[3], one 64^3 x 4 -> 512^3 "
+                         "volume through the three 8x generators, slices sharded over the ranks")
     ap.add_argument("--launch-timeout", type=float, default=3000.0)
     return ap.parse_args(argv)
 
@@ -262,11 +269,93 @@ def cpu_baseline_and_parity(p1, p2, low, gpu_runs, slices=12):
     return base, parity, idx
 
 
+C4_CFG = [dict(first_gen=True, filter_size=3, start_fms=256, max_fms=256, add_adj=True, first_nn_arch=True, use_res_net=True),
+          dict(first_gen=False, filter_size=5, start_fms=192, max_fms=192, use_res_net=True),
+          dict(first_gen=False, filter_size=5, start_fms=192, max_fms=96, use_res_net=False)]    # example_run_output.py:18-47
+C4_GFLOP_PER_SLICE = [136.63, 405.48, 397.21]
+
+
+def main_c4(args):
+    """BASELINE configs[3]: 8x three-pass inference, 64^3 density + velocity -> 512^3, the slices of every pass sharded over
+    the ranks (multipass.multipass_8x with `comm`), same JSON shape as the headline.  One step = one volume (strong
+    scaling: the volume is what it is; with N ranks every rank evaluates 512 / N slices per pass)."""
+    import torch
+    import mpgan_amd  # noqa: F401
+    from mpgan_amd import dist as mdist
+    from mpgan_amd import multipass as MP
+    from mpgan_amd.synthetic import synthetic_volume
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    comm, device = mdist.init_from_env()
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    torch.cuda.set_device(device)
+    MP.set_pass_lanes(args.lanes)
+    gens = [MP.Generator("growing_gen", dict(tile_low=SIM, up_res=8, channels=4, **c), None, args.prec, device=device, seed=100 + i)
+            for i, c in enumerate(C4_CFG)]
+    low = torch.as_tensor(synthetic_volume(SIM, 4, 0)).to(device)
+
+    def timed(exchange):
+        step = lambda: MP.multipass_8x(gens, low, 8, batches=(8, 2, 2), comm=comm, exchange=exchange)
+        for _ in range(args.warmup):
+            step()
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        torch.cuda.synchronize(device)
+        if comm is not None:
+            comm.barrier()
+        dt = time.perf_counter() - t0
+        return (comm.max_float(dt, device) if comm is not None else dt), out
+    try:
+        dt, out = timed(args.exchange)
+    except Exception as e:                       # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else "")
+        sys.stderr.write("bench.py rank %d: the sharded run failed (%s)\n" % (rank, err))
+        if rank == 0:
+            print(json.dumps(failed_line(args, err)))
+            sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)
+    extra = {}
+    if world > 1 and args.mode == "both":
+        other = "all_to_all" if args.exchange == "all_gather" else "all_gather"
+        dto, _ = timed(other)
+        extra["value_" + other] = round(args.steps / dto, 4)
+    if rank != 0:
+        return 0
+    s8 = SIM * 8
+    tflop = sum(C4_GFLOP_PER_SLICE) * s8 / 1e3
+    res = {
+        "metric": "volumes/sec (8x three-pass generator inference, 64^3->512^3 density+velocity)",
+        "value": round(args.steps / dt, 4), "unit": "volumes/s", "n_gpus": world, "rccl_ranks": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": DTYPE_NAME[args.prec], "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: 8x three-pass growing_gen inference (example_run_output.py:18-47), one "
+                               "64^3 x 4-channel volume -> 512^3 per step", "slices_per_volume": 3 * s8, "lanes": max(args.lanes, 1),
+                   "parallelism": ("slice-axis sharding x%d + %s between passes" % (world, args.exchange)) if world > 1 else "single GPU"},
+        "slices_per_s": round(3 * s8 * args.steps / dt, 2),
+        "algorithmic_tflops": round(tflop * args.steps / dt, 2),
+        "checksum_volume": float(out.double().sum().item()),
+    }
+    res.update(extra)
+    print(json.dumps(res))
+    sys.stdout.flush()
+    return 0
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_self(args, argv))
+    if args.workload == "c4":
+        return main_c4(args)
 
     import torch
     import mpgan_amd
@@ -293,7 +382,7 @@ def main(argv=None):
     lows = [torch.as_tensor(v).to(device) for v in lows_np]       # resident in HBM before the timed region
     mine = lows[rank * args.volumes_per_gpu:(rank + 1) * args.volumes_per_gpu]
 
-    def timed(ga, gb, replicas):
+    def timed(ga, gb, replicas, exchange=args.exchange):
         """W warm-up steps, then exactly K steps between barrier + synchronize; max over ranks"""
         lanes = [(ga.clone(), gb.clone()) for _ in range(max(args.lanes, 1) - 1)]
 
@@ -302,7 +391,7 @@ def main(argv=None):
             # one volume's slabs overlaps the convolutions of its neighbours (N > 1); same arithmetic either way
             if replicas:
                 return MP.two_pass_4x_batch(ga, gb, mine, UP, batch=args.slice_batch, comm=None, lanes=lanes)
-            return MP.two_pass_4x_batch(ga, gb, lows, UP, batch=args.slice_batch, comm=comm, lanes=lanes)
+            return MP.two_pass_4x_batch(ga, gb, lows, UP, batch=args.slice_batch, comm=comm, lanes=lanes, exchange=exchange)
         for _ in range(args.warmup):
             step()
         if comm is not None:
@@ -344,6 +433,10 @@ def main(argv=None):
         del o
         extra["value_replicas"] = round(n_vol * args.steps / dt_r, 4)
         extra["ms_per_step_replicas"] = round(dt_r / args.steps * 1e3, 3)
+        other = "all_to_all" if args.exchange == "all_gather" else "all_gather"
+        dt_o, o = timed(g1, g2, replicas=False, exchange=other)
+        del o
+        extra["value_" + other] = round(n_vol * args.steps / dt_o, 4)
     second = None
     if not args.no_second_prec and args.prec != 3:
         r1 = MP.Generator("gen_resnet", cfg1, g1.params(), 3, device=device)
@@ -380,7 +473,7 @@ def main(argv=None):
             "slice_batch": args.slice_batch,
             "lanes": max(args.lanes, 1),
             "parallelism": ("whole volumes per rank x%d, no exchange" % world if replicas_only else
-                            "slice-axis sharding x%d + all-gather between passes, exchanges overlapped with the next volume" % world)
+                            "slice-axis sharding x%d + %s between passes, exchanges overlapped with the next volume" % (world, args.exchange))
                            if world > 1 else "single GPU",
             "precision": {3: "MPG_PREC_F16X3 (fp16 hi/lo split, three fp16 MFMA products, fp32 accumulate)",
                           2: "MPG_PREC_F16F6 (fp16 product + two bf6 MX block-scaled correction products, fp32 accumulate; the "

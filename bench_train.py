@@ -24,7 +24,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
 
 DENSE_F16_MFMA_PEAK_TFLOPS = 2500.0
 
@@ -110,6 +109,7 @@ def cpu_baseline(tile, batch, c, seed):
 
 
 def main():
+    global torch                      # imported below, after the GPU-free launcher branch
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=("c3", "c5"))
@@ -120,7 +120,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without torch.distributed.run: this process never touches the GPU; it starts one fresh rank per GPU
+        # (mpgan_amd.launch), relays rank 0's JSON line and exits with the worst return code -- never a re-exec
+        from mpgan_amd import launch
+        rc, out = launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout)
+        line = launch.last_json_line(out)
+        if line is not None:
+            print(line)
+        else:
+            sys.stderr.write(out)
+            rc = rc or 1
+        sys.stdout.flush()
+        sys.exit(rc)
+    import torch
     from mpgan_amd import _lib
     from mpgan_amd import dist as mdist
     from mpgan_amd.train import Trainer4x, Trainer8x

@@ -134,6 +134,36 @@ int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, int kh, int 
 
 int mpg_conv2d_fused(mpg_stream_t stream, const mpg_conv_desc* desc);
 
+/* A whole residual block whose three convolutions have <= 8 channels on either side, as ONE launch:
+ *     y = act_b( conv_b( act_a( conv_a(up(x)) + bias_a ) ) + conv_s(up(x)) + bias_b )
+ * (resBlock 0 and 3 of gen_resnet, 1 -> 2 -> 8 and 8 -> 2 -> 1 channels: GAN/multipassGAN-4x.py:505-526,560,564).
+ * The middle tensor stays in LDS (as two mpg_conv2d_fused launches it made a round trip through HBM).  fp32
+ * arithmetic on the exact (hi16 + lo16) inputs whatever `prec` says; wpack_* come from mpg_conv_pack_weights
+ * with that `prec` (the fp32 tables of small layers follow the matrix-core image).  Odd filters only. */
+typedef struct mpg_small_pair_desc {
+    int32_t n, h, w;          /* output batch / height / width */
+    const void* x;            /* G8 input [N][cgroups][2][H>>up_log2][W>>up_log2][8]; one channel group is read */
+    int32_t cin, cgroups, g_off, up_log2;
+    const void* wpack_a;      /* conv_a: kh_a x kw_a, cin -> cmid */
+    int32_t kh_a, kw_a, cmid;
+    const float* bias_a;      /* [cmid] or NULL */
+    int32_t act_a;
+    float   leak_a;
+    const void* wpack_b;      /* conv_b: kh_b x kw_b, cmid -> cout */
+    int32_t kh_b, kw_b;
+    const void* wpack_s;      /* shortcut conv_s: kh_s x kw_s, cin -> cout, or NULL */
+    int32_t kh_s, kw_s;
+    const float* bias_b;      /* [cout] or NULL (bias of conv_b plus bias of conv_s) */
+    int32_t act_b;
+    float   leak_b;
+    int32_t cout;
+    float*  y;                /* fp32 NHWC [N,H,W,cout] or NULL */
+    void*   y_g8;             /* G8 (one group) or NULL; at least one of the two */
+    int32_t prec;             /* MPG_PREC_* the weights were packed for */
+    int32_t reserved;         /* must be 0 */
+} mpg_small_pair_desc;
+int mpg_conv2d_small_pair(mpg_stream_t stream, const mpg_small_pair_desc* desc);
+
 /* out[0] = max |x_i| (device float).  mpg_f32_to_g8_scaled converts x * 2^k with 2^k = the power of two that brings
  * that maximum into [2^8, 2^9); a convolution over such an input takes the same pointer in desc.in_amax. */
 int mpg_absmax(mpg_stream_t stream, const float* x, size_t n, float* out);

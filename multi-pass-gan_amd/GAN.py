@@ -173,14 +173,16 @@ class GAN(object):
         _say("Avg Depool {}: {}".format(window_size, self.layer.get_shape()))
         return self.layer
 
-    # GAN.py:554-560: a 3x3 linear convolution to depth_factor^2 * C channels, then tf.depth_to_space
+    # GAN.py:554-560: a [1,1] linear convolution to C * 4 channels (a fixed 4, whatever `upres` is; no batch norm:
+    # variable g_cPS<stage>/weight [1,1,C,4C]), then tf.depth_to_space(upres).  As in the reference, upres != 2 only
+    # works when 4C is a multiple of upres^2.
     def pixel_shuffle(self, input_layer=None, upres=2, stage="1"):
         if input_layer is None:
             input_layer = self.layer
-        out_ch = int(input_layer.get_shape()[-1])
-        self.convolutional_layer(out_ch * upres * upres, [3, 3], None, stride=[1], name="g_cPS" + stage,
-                                 in_layer=input_layer)
-        self.layer = G.depth_to_space(self.layer, upres)
+        in_ch = int(input_layer.get_shape()[-1])
+        lin, _ = self.convolutional_layer(in_ch * 4, [1, 1], None, stride=[1], name="g_cPS" + stage,
+                                          in_layer=input_layer, batch_norm=False)
+        self.layer = G.depth_to_space(lin, upres)
         return self.layer
 
     # GAN.py:566-619, deconv2d :703-708.  As written, the reference cannot execute this method: it passes `init_mean` to
@@ -226,9 +228,9 @@ class GAN(object):
     # GAN.py:624-631
     def noise(self, channels=-1):
         # as many noise channels as the layer has, or `channels` of them, N(0, 0.04), appended on the channel axis
+        # (the reference does not count this as a layer: layer_num stays; the generator's seed is the node's own id)
         nch = int(channels) if channels > 0 else int(self.layer.get_shape()[-1])
-        self.layer_num += 1
-        noise = G.random_normal_like(self.layer, nch, 0.04, seed=self.layer_num)
+        noise = G.random_normal_like(self.layer, nch, 0.04, seed=None)
         self.layer = G.concat([self.layer, noise], axis=-1)
         _say("Noise {}: {}".format(noise.get_shape(), self.layer.get_shape()))
         return self.layer

@@ -71,6 +71,27 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class SmallPairDesc(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32),
+        ("x", ctypes.c_void_p),
+        ("cin", ctypes.c_int32), ("cgroups", ctypes.c_int32), ("g_off", ctypes.c_int32), ("up_log2", ctypes.c_int32),
+        ("wpack_a", ctypes.c_void_p),
+        ("kh_a", ctypes.c_int32), ("kw_a", ctypes.c_int32), ("cmid", ctypes.c_int32),
+        ("bias_a", ctypes.c_void_p),
+        ("act_a", ctypes.c_int32), ("leak_a", ctypes.c_float),
+        ("wpack_b", ctypes.c_void_p),
+        ("kh_b", ctypes.c_int32), ("kw_b", ctypes.c_int32),
+        ("wpack_s", ctypes.c_void_p),
+        ("kh_s", ctypes.c_int32), ("kw_s", ctypes.c_int32),
+        ("bias_b", ctypes.c_void_p),
+        ("act_b", ctypes.c_int32), ("leak_b", ctypes.c_float), ("cout", ctypes.c_int32),
+        ("y", ctypes.c_void_p),
+        ("y_g8", ctypes.c_void_p),
+        ("prec", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _Z = ctypes.c_size_t
@@ -89,6 +110,7 @@ PROTOTYPES = {
     "mpg_conv_pack_size": (_Z, [_I, _I, _I, _I, _I]),
     "mpg_conv_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _Z]),
     "mpg_conv2d_fused": (_I, [_P, ctypes.POINTER(ConvDesc)]),
+    "mpg_conv2d_small_pair": (_I, [_P, ctypes.POINTER(SmallPairDesc)]),
     "mpg_conv2d_direct": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _F, _P]),
     "mpg_resize_nearest": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),
     "mpg_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),

@@ -33,6 +33,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_AH
 #define MPG_AH 2
 #endif
+// development switches of the F16F6 K loop (tools/build_variants.sh builds one library per setting, tools/probe_variants.py
+// times them against each other on one box):
+//   MPG_WD          bf6 weight planes read MPG_WD correction steps ahead of their MFMAs (MPG_WD + 1 register buffers)
+//   MPG_DIAG6       timing-only builds (results are garbage): 1 = no correction phase at all, 2 = no block-scale / conversion
+//                   VALU work (the bf6 operands are whatever the fp16 fragments hold)
+#ifndef MPG_WD
+#define MPG_WD 1
+#endif
+//   MPG_W4 1        four cout tiles: 4 waves x (4 tile rows x 4 cout tiles), ONE wave per SIMD with 256 accumulator
+//                   registers (no arbitration between two waves of a SIMD, a third fewer A-fragment reads) instead of 8 x (2 x 4)
+#ifndef MPG_W4
+#define MPG_W4 0
+#endif
+#ifndef MPG_DIAG6
+#define MPG_DIAG6 0
+#endif
+//   MPG_STAMPS 1    diagnostic build only: every wave accumulates, over the stages of its K loop, the s_memtime cycles from
+//                   the barrier release to (0) its first MFMA wait satisfied, (1) the end of the fp16 groups, (2) the end
+//                   of the correction steps, (3) the release of the next barrier, and writes the four sums to
+//                   y[(block * WAVES + wave) * 4 ..] when desc.reserved has bit 3 set (tools/probe_stamps.py)
+#ifndef MPG_STAMPS
+#define MPG_STAMPS 0
+#endif
+#if MPG_STAMPS
+#define MPG_STAMP(v) asm volatile("s_memtime %0" : "=s"(v))
+#else
+#define MPG_STAMP(v)
+#endif
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
@@ -488,7 +516,7 @@ constexpr int BF6 = 3;     // cbsz / blgp code of e3m2
 
 template <int NT>
 struct Pipe6 {
-    static constexpr int WAVES = (NT == 1) ? 4 : 8;
+    static constexpr int WAVES = (NT == 1 || (NT == 4 && MPG_W4)) ? 4 : 8;
     static constexpr int PT = 16 / WAVES;                  // tile rows per wave
     static constexpr int TH = 16;
     static constexpr int WF16 = 4 * NT * 1024;             // four fp16 k-steps
@@ -501,7 +529,7 @@ struct Pipe6 {
 };
 
 template <int NT>
-__global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(const ConvArgs a_unused) {
+__global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, (NT == 4 && MPG_W4) ? 1 : 2) void conv_mfma_f6_kernel(const ConvArgs a_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const auto& a = *ap;
@@ -576,48 +604,54 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 const char* wb = w_lds + (st % R) * WSTAGE;
                 const char* xs = xb + (size_t)st * 8 * gstride;   // uniform: first group of this macro-step
                 const int grem = glast - st * 8;
-                half8 b_hi[4][PT], b_lo[4][PT];
+                // one (four tile rows per wave) or two tile rows at a time: all 32 operand fragments of a macro-step would not
+                // fit next to the accumulators (the weights are re-read from LDS for every part)
+                constexpr int PH = PT == 4 ? 1 : 2;
+                static_for<0, PT / PH>([&](auto hc) {
+                    constexpr int p0 = decltype(hc)::value * PH;
+                    half8 b_hi[4][PH], b_lo[4][PH];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int g = 2 * j + hh;
-                    g = g < grem ? g : grem;                 // groups past the segment: zero weights
+                    for (int j = 0; j < 4; ++j) {
+                        int g = 2 * j + hh;
+                        g = g < grem ? g : grem;                 // groups past the segment: zero weights
 #pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        b_hi[j][pt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride)));   // read once
-                        b_lo[j][pt] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[pt] + g * gstride + plane_bytes)));
+                        for (int q = 0; q < PH; ++q) {
+                            b_hi[j][q] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[p0 + q] + g * gstride)));   // read once
+                            b_lo[j][q] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(xs + (pixo[p0 + q] + g * gstride + plane_bytes)));
+                        }
                     }
-                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+#pragma unroll
+                            for (int q = 0; q < PH; ++q)
+                                acc[p0 + q][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[j][q], acc[p0 + q][nt], 0, 0, 0);
+                        }
+                    }
+                    v8i hi6[PH], lo6[PH];
+                    int sb[PH];
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        const half32 bh = cat32(b_hi[0][q], b_hi[1][q], b_hi[2][q], b_hi[3][q]);
+                        const half32 bl = cat32(b_lo[0][q], b_lo[1][q], b_lo[2][q], b_lo[3][q]);
+                        const int e = block_exp16(bh);
+                        hi6[q] = bf6_of(bh, e + 109);
+                        lo6[q] = bf6_of(bl, e + 97);
+                        sb[q] = (e + 109) | (e + 97) << 8;
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const half8 a_hi = *reinterpret_cast<const half8*>(wb + ((j * NT + nt) * 64 + lane) * 16);
+                        const v8i w_hi = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
+                        const v8i w_lo = lds_read32(wb + WF16 + WF6 + nt * 2048 + lane * 16);
 #pragma unroll
-                        for (int pt = 0; pt < PT; ++pt)
-                            acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi[j][pt], acc[pt][nt], 0, 0, 0);
+                        for (int q = 0; q < PH; ++q) {
+                            acc[p0 + q][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_lo, hi6[q], acc[p0 + q][nt], BF6, BF6, 1, w_lo[6], 0, sb[q]);
+                            acc[p0 + q][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_hi, lo6[q], acc[p0 + q][nt], BF6, BF6, 0, w_hi[6], 1, sb[q]);
+                        }
                     }
-                }
-                v8i hi6[PT], lo6[PT];
-                int sb[PT];
-#pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    const half32 bh = cat32(b_hi[0][pt], b_hi[1][pt], b_hi[2][pt], b_hi[3][pt]);
-                    const half32 bl = cat32(b_lo[0][pt], b_lo[1][pt], b_lo[2][pt], b_lo[3][pt]);
-                    const int e = block_exp16(bh);
-                    hi6[pt] = bf6_of(bh, e + 109);
-                    lo6[pt] = bf6_of(bl, e + 97);
-                    sb[pt] = (e + 109) | (e + 97) << 8;
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const v8i w_hi = lds_read32(wb + WF16 + nt * 2048 + lane * 16);
-                    const v8i w_lo = lds_read32(wb + WF16 + WF6 + nt * 2048 + lane * 16);
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt) {
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_lo, hi6[pt], acc[pt][nt], BF6, BF6, 1, w_lo[6], 0, sb[pt]);
-                        acc[pt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w_hi, lo6[pt], acc[pt][nt], BF6, BF6, 0, w_hi[6], 1, sb[pt]);
-                    }
-                }
+                });
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -636,11 +670,15 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
         for (int q = tid; q < NS * 8; q += THREADS) {
             const int g = q / sg.tp;
             const int t = q - g * sg.tp;
-            int off = 0;
+            // Padding slots (t >= T, or past the last group) have zero weights but their pixels still enter the lane's
+            // block maximum, i.e. the scale of the REAL values of the block: they must read stable data.  They read tap
+            // (0, 0) of the image of the group they pad -- resident for the whole stage -- never the other buffer, which
+            // may be receiving the next group's image by DMA at that moment (run-to-run differences in the last bits).
+            int off = ((g < G ? g : G - 1) & 1) * a.img_bytes;
             if (g < G && t < T) {
                 const int dy = t / sg.kw;
                 const int dx = t - dy * sg.kw;
-                off = (g & 1) * a.img_bytes + (dy * sg.iw + dx) * 16;
+                off += (dy * sg.iw + dx) * 16;
             }
             tap16[(q >> 3) * 8 + (q & 1) * 4 + ((q & 7) >> 1)] = off;             // [stage][half][k-step]
         }
@@ -693,11 +731,25 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
         half8 bh[PT][4];
         v4i o16n = {0, 0, 0, 0};
         const unsigned i_base = lds_off(img_lds);
+#if MPG_STAMPS
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts3_prev = 0;
+        unsigned sum_head = 0, sum_f16 = 0, sum_f6 = 0, sum_bar = 0;
+#endif
 
         for (int st = 0; st < NS; ++st) {
             // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
             // with stage st-1
             wait_dma_and_barrier<(D - 1) * NI>();
+#if MPG_STAMPS
+            if (st > 0) {       // the barrier's lgkmcnt(0) completed every stamp of the previous stage
+                sum_head += (unsigned)(ts1 - ts0);
+                sum_f16 += (unsigned)(ts2 - ts1);
+                sum_f6 += (unsigned)(ts3 - ts2);
+                if (st > 1) sum_bar += (unsigned)(ts0 - ts3_prev);
+                ts3_prev = ts3;
+            }
+            MPG_STAMP(ts0);
+#endif
             // the tap table is constant over the segment: stage st + 1's entry is read at the head of stage st
             if (st == 0) {
                 ds_read16<0>(o16n, lds_off(tap16 + hh * 4));
@@ -739,10 +791,17 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
             };
             auto make_hi6 = [&](auto pc) {
                 constexpr int pt = decltype(pc)::value;
+#if MPG_DIAG6 & 2
+                const v4i q0 = __builtin_bit_cast(v4i, bh[pt][0]), q1 = __builtin_bit_cast(v4i, bh[pt][1]);
+                hi6[pt] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+                e16[pt] = 15;
+                sb[pt] = 0x7f7f7f7f;
+#else
                 const half32 b32 = cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]);
                 e16[pt] = block_exp16(b32);
                 hi6[pt] = bf6_of(b32, e16[pt] + 109);
                 sb[pt] = (e16[pt] + 109) | (e16[pt] + 97) << 8;
+#endif
             };
             static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
             constexpr int HALF = G16 / 2;
@@ -765,6 +824,7 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 }
                 if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
                 lgkm_wait<kx_allowed(g, NT, PT, AH)>();        // reads issued behind group g's own
+                if constexpr (g == 0) { MPG_STAMP(ts1); }
                 tie(aq[g % (AH + 1)]);
                 if constexpr (nt == 0)
                     static_for<0, PT>([&](auto pc) { tie(bh[decltype(pc)::value][j]); });
@@ -777,16 +837,20 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 if constexpr (g >= 3 * NT && g - 3 * NT < PT) make_hi6(std::integral_constant<int, g - 3 * NT>{});
                 if constexpr (g == G16 - 1 && NT < PT) static_for<NT, PT>([&](auto pc) { make_hi6(pc); });
             });
+            MPG_STAMP(ts2);
             // ---- the two bf6 corrections: step k < NT is w_lo6[k] x a_hi6, step k >= NT is w_hi6[k - NT] x a_lo6 ----
             // LDS reads in order: W(0), the a_lo fragments of the first two tile rows (into the registers of their a_hi
-            // ones, which the conversions above have consumed), W(1), then W(k + 1) ahead of step k.
+            // ones, which the conversions above have consumed), W(1) .. W(WD), then W(k + WD) ahead of step k.
+#if !(MPG_DIAG6 & 1)
             constexpr int PB = PT < 2 ? PT : 2;
-            v4i wq[2][2];
+            constexpr int KS6 = 2 * NT;                            // correction steps
+            constexpr int WD = MPG_WD < KS6 - 1 ? MPG_WD : KS6 - 1;
+            v4i wq[WD + 1][2];
             auto read_w6 = [&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int off = WF16 + (k < NT ? WF6 + k * 2048 : (k - NT) * 2048);
-                ds_read16<off>(wq[k & 1][0], a_base);
-                ds_read16<off + 1024>(wq[k & 1][1], a_base);
+                ds_read16<off>(wq[k % (WD + 1)][0], a_base);
+                ds_read16<off + 1024>(wq[k % (WD + 1)][1], a_base);
             };
             auto read_bl = [&](auto pc) {
                 constexpr int pt = decltype(pc)::value;
@@ -798,17 +862,24 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
             auto make_lo6 = [&](auto pc) {
                 constexpr int pt = decltype(pc)::value;
                 static_for<0, 4>([&](auto jc) { tie(bh[pt][decltype(jc)::value]); });
+#if MPG_DIAG6 & 2
+                const v4i q0 = __builtin_bit_cast(v4i, bh[pt][0]), q1 = __builtin_bit_cast(v4i, bh[pt][1]);
+                lo6[pt] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7);
+#else
                 lo6[pt] = bf6_of(cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]), e16[pt] + 97);
+#endif
             };
             read_w6(std::integral_constant<int, 0>{});
             static_for<0, PB>([&](auto pc) { read_bl(pc); });
-            read_w6(std::integral_constant<int, 1>{});
-            static_for<0, 2 * NT>([&](auto kc) {
+            static_for<1, WD + 1>([&](auto kc) { read_w6(kc); });
+            static_for<0, KS6>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                if constexpr (k >= 1 && k + 1 < 2 * NT) read_w6(std::integral_constant<int, k + 1>{});
-                lgkm_wait<(k == 0 ? 4 * PB + 2 : (k + 1 < 2 * NT ? 2 : 0))>();
-                tie(wq[k & 1][0]);
-                tie(wq[k & 1][1]);
+                if constexpr (k >= 1 && k + WD < KS6) read_w6(std::integral_constant<int, k + WD>{});
+                // reads issued behind W(k): at k = 0 the a_lo fragments and W(1 .. WD), later W(k + 1 .. k + WD)
+                constexpr int ahead = (k + WD < KS6 ? k + WD : KS6 - 1) - k;
+                lgkm_wait<(k == 0 ? 4 * PB : 0) + 2 * ahead>();
+                tie(wq[k % (WD + 1)][0]);
+                tie(wq[k % (WD + 1)][1]);
                 if constexpr (k == 1) {
                     static_for<0, PB>([&](auto pc) { make_lo6(pc); });
                     if constexpr (PT > PB) {           // four tile rows per wave (one cout tile): the other two, exposed
@@ -817,7 +888,7 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                         static_for<PB, PT>([&](auto pc) { make_lo6(pc); });
                     }
                 }
-                const v8i w6 = __builtin_shufflevector(wq[k & 1][0], wq[k & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                const v8i w6 = __builtin_shufflevector(wq[k % (WD + 1)][0], wq[k % (WD + 1)][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 static_for<0, PT>([&](auto pc) {
                     constexpr int pt = decltype(pc)::value;
                     if constexpr (k < NT)
@@ -826,9 +897,19 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                         acc[pt][k - NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, lo6[pt], acc[pt][k - NT], BF6, BF6, 0, w6[6], 1, sb[pt]);
                 });
             });
+#else
+            asm volatile("" ::"v"(hi6[0]), "v"(sb[0]), "v"(e16[0]));
+#endif
+            MPG_STAMP(ts3);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+#if MPG_STAMPS
+        if ((a.dbg & 8) && a.y != nullptr && s == 0 && lane == 0) {
+            unsigned* o = reinterpret_cast<unsigned*>(a.y) + ((size_t)blockIdx.x * WAVES + wave) * 4;
+            o[0] = sum_head; o[1] = sum_f16; o[2] = sum_f6; o[3] = sum_bar;
+        }
+#endif
     }
     conv_epilogue<NT, PT>(acc, ap, smem, n, y0, x0, wave, lane);
 }
@@ -1099,39 +1180,36 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
                 }
             }
         }
-    }
 #if MPG_DIAG_SMALL
-    {   // diagnostic: is this block's LDS still what it wrote?  (foreign writes into the allocation)
-        __syncthreads();
-        const SmallSeg& g = a.seg[a.nseg - 1];
-        const size_t plane_bytes = (size_t)g.hs * g.ws * 16;
-        const char* base = g.x + ((size_t)b * g.cg_total + g.g_off) * 2 * plane_bytes;
-        const int tw = SM_TW + g.kw - 1, th = SM_TH + g.kh - 1;
-        unsigned bad_w = 0, bad_t = 0;
-        for (int p = tid; p < g.kh * g.kw * CINB * COUT; p += 256) {
-            const int co = p % COUT, ci = (p / COUT) % CINB, tap = p / (COUT * CINB);
-            if (wl[p] != g.w[tap * 64 + ci * 8 + co]) ++bad_w;
-        }
-        for (int p = tid; p < tw * th; p += 256) {
-            const int hy = p / tw, hx = p - hy * tw;
-            const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
-            float v[8];
-            if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
-                g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, v);
-            } else {
-                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+        {   // diagnostic: is this block's LDS still what it wrote?  (foreign writes into the allocation; checked for EVERY
+            // segment right after its sums, before the next segment overwrites the table and the tile)
+            __syncthreads();
+            unsigned bad_w = 0, bad_t = 0;
+            for (int p = tid; p < g.kh * g.kw * CINB * COUT; p += 256) {
+                const int co = p % COUT, ci = (p / COUT) % CINB, tap = p / (COUT * CINB);
+                if (wl[p] != g.w[tap * 64 + ci * 8 + co]) ++bad_w;
             }
-            const float4 t0 = tile[p];
-            if (t0.x != v[0] || t0.y != v[1] || t0.z != v[2] || t0.w != v[3]) ++bad_t;
-            if (PL > 1) {
-                const float4 t1 = tile[th * tw + p];
-                if (t1.x != v[4] || t1.y != v[5] || t1.z != v[6] || t1.w != v[7]) ++bad_t;
+            for (int p = tid; p < tw * th; p += 256) {
+                const int hy = p / tw, hx = p - hy * tw;
+                const int yy = y0 - g.pt + hy, xx = x0 - g.pl + hx;
+                float v[8];
+                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
+                    g8_load8(base + ((size_t)(yy >> g.up) * g.ws + (xx >> g.up)) * 16, plane_bytes, v);
+                } else {
+                    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+                }
+                const float4 t0 = tile[p];
+                if (t0.x != v[0] || t0.y != v[1] || t0.z != v[2] || t0.w != v[3]) ++bad_t;
+                if (PL > 1) {
+                    const float4 t1 = tile[th * tw + p];
+                    if (t1.x != v[4] || t1.y != v[5] || t1.z != v[6] || t1.w != v[7]) ++bad_t;
+                }
             }
+            if (bad_w) atomicAdd(&g_small_diag[0], bad_w);
+            if (bad_t) atomicAdd(&g_small_diag[1], bad_t);
         }
-        if (bad_w) atomicAdd(&g_small_diag[0], bad_w);
-        if (bad_t) atomicAdd(&g_small_diag[1], bad_t);
-    }
 #endif
+    }
     const int x = x0 + lx;
     if (x >= a.w) return;
     const float unscale = a.in_amax != nullptr ? 1.f / mpg::pow2_scale(*a.in_amax) : 1.f;
@@ -1146,6 +1224,189 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
             o[q] = (q < COUT && q < a.cout) ? mpg::apply_act(acc[j][q < COUT ? q : 0] * unscale + (a.bias != nullptr ? a.bias[q] : 0.f),
                                                               a.act, a.leak)
                                             : 0.f;
+        const size_t pix = (size_t)y * a.w + x;
+        if (a.y != nullptr) {
+            float* dst = a.y + ((size_t)b * plane_px + pix) * a.cout;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < a.cout) dst[q] = o[q];
+        }
+        if (a.y_g8 != nullptr) {
+            half8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                hi[q] = (_Float16)o[q];
+                lo[q] = (_Float16)(o[q] - (float)hi[q]);
+            }
+            char* dst = a.y_g8 + ((size_t)b * 2 * plane_px + pix) * 16;
+            *reinterpret_cast<half8*>(dst) = hi;
+            *reinterpret_cast<half8*>(dst + plane_px * 16) = lo;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv_small_pair_kernel: a residual block whose three convolutions all have <= 8 channels on either side -- the first
+// and the last block of gen_resnet, relu(convB(relu(convA(x))) + conv1x1(x)) with 1 -> 2 -> 8 and 8 -> 2 -> 1 channels
+// (GAN/multipassGAN-4x.py:505-526,560,564) -- as ONE launch.  The block's middle tensor never leaves the CU: stage A is
+// evaluated on the output tile plus the halo of filter B (68 x 20 pixels for a 64 x 16 tile and a 5x5 filter) into LDS,
+// stage B and the shortcut read it and the input tile from there.  As two launches the middle tensor made a round
+// trip through HBM in the G8 layout (32 bytes per pixel written and read for two channels) and the second launch
+// waited for the last block of the first.
+// A thread owns a column of SM_RPT pixels in both stages (see conv_small_kernel).  Middle pixels outside the image
+// are zero: filter B sees the SAME padding of a tensor of the image's size, not an extension of stage A.
+// ---------------------------------------------------------------------------------------------
+struct PairArgs {
+    int n, h, w;
+    const char* x;                 // G8 input, one channel group
+    int cg_total, g_off, up, hs, ws;
+    const float *wa, *wb, *wsc;    // [tap][8][8] tables: stage A (cin -> cmid), stage B (cmid -> cout), shortcut (cin -> cout) or null
+    int kha, kwa, pta, pla;        // filter A and its SAME padding before
+    int khb, kwb, ptb, plb;
+    int khs, kws, pts, pls;
+    const float *bias_a, *bias_b;
+    int act_a, act_b;
+    float leak_a, leak_b;
+    int cout;
+    float* y;
+    char* y_g8;
+    int x_px, mid_px;              // pixels of the input tile / of the middle tile (LDS plane sizes)
+};
+
+// sums of one filter over a column of SM_RPT pixels: tile = planes of four channels [plane][row][col] (float4), the
+// thread's first row is `row0`, its column `col` (both in tile coordinates of the first tap); wl = [tap][CINB][COUTB]
+template <int CINB, int COUTB>
+__device__ __forceinline__ void small_column(const float4* tile, int tw, int plane_px, int row0, int col, const float* wl,
+                                             int kh, int kw, float (&acc)[SM_RPT][COUTB]) {
+    constexpr int PL = (CINB + 3) / 4, CP = CINB < 4 ? CINB : 4;
+    for (int kx = 0; kx < kw; ++kx) {
+        float rows[SM_RPT + SM_KMAX - 1][CINB];
+#pragma unroll
+        for (int r = 0; r < SM_RPT + SM_KMAX - 1; ++r) {
+            if (r < SM_RPT + kh - 1) {
+                const float4* src = tile + (row0 + r) * tw + col + kx;
+                const float4 p0 = src[0];
+                rows[r][0] = p0.x;
+                if (CP > 1) rows[r][1] = p0.y;
+                if (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
+                if (PL > 1) {
+                    const float4 p1 = src[plane_px];
+                    rows[r][4] = p1.x; rows[r][5] = p1.y; rows[r][6] = p1.z; rows[r][7] = p1.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < SM_KMAX; ++ky) {
+            if (ky < kh) {
+                const float* wt = wl + (ky * kw + kx) * (CINB * COUTB);
+#pragma unroll
+                for (int ci = 0; ci < CINB; ++ci) {
+                    float wv[COUTB];
+#pragma unroll
+                    for (int co = 0; co < COUTB; ++co) wv[co] = wt[ci * COUTB + co];
+#pragma unroll
+                    for (int j = 0; j < SM_RPT; ++j)
+#pragma unroll
+                        for (int co = 0; co < COUTB; ++co) acc[j][co] = fmaf(rows[j + ky][ci], wv[co], acc[j][co]);
+                }
+            }
+        }
+    }
+}
+
+template <int CINB, int CMIDB, int COUTB>
+__global__ __launch_bounds__(256) void conv_small_pair_kernel(PairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float small_lds[];
+    constexpr int PLX = (CINB + 3) / 4, PLM = (CMIDB + 3) / 4;
+    float4* xt = reinterpret_cast<float4*>(small_lds);               // input tile: PLX planes of x_px pixels
+    float4* mt = xt + PLX * a.x_px;                                   // middle tile: PLM planes of mid_px pixels
+    float* wla = reinterpret_cast<float*>(mt + PLM * a.mid_px);       // [tap][CINB][CMIDB]
+    float* wlb = wla + a.kha * a.kwa * CINB * CMIDB;                  // [tap][CMIDB][COUTB]
+    float* wls = wlb + a.khb * a.kwb * CMIDB * COUTB;                 // [tap][CINB][COUTB]
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * SM_TW, y0 = blockIdx.y * SM_TH, b = blockIdx.z;
+    const int mw = SM_TW + a.kwb - 1, mh = SM_TH + a.khb - 1;         // middle tile
+    const int xw = mw + a.kwa - 1, xh = mh + a.kha - 1;               // input tile
+    const int mx0 = x0 - a.plb, my0 = y0 - a.ptb;                     // image coordinates of the tiles' first pixels
+    const int xx0 = mx0 - a.pla, xy0 = my0 - a.pta;
+    for (int p = tid; p < a.kha * a.kwa * CINB * CMIDB; p += 256) {
+        const int co = p % CMIDB, ci = (p / CMIDB) % CINB, tap = p / (CMIDB * CINB);
+        wla[p] = a.wa[tap * 64 + ci * 8 + co];
+    }
+    for (int p = tid; p < a.khb * a.kwb * CMIDB * COUTB; p += 256) {
+        const int co = p % COUTB, ci = (p / COUTB) % CMIDB, tap = p / (COUTB * CMIDB);
+        wlb[p] = a.wb[tap * 64 + ci * 8 + co];
+    }
+    if (a.wsc != nullptr)
+        for (int p = tid; p < a.khs * a.kws * CINB * COUTB; p += 256) {
+            const int co = p % COUTB, ci = (p / COUTB) % CINB, tap = p / (COUTB * CINB);
+            wls[p] = a.wsc[tap * 64 + ci * 8 + co];
+        }
+    {
+        const size_t plane_bytes = (size_t)a.hs * a.ws * 16;
+        const char* base = a.x + ((size_t)b * a.cg_total + a.g_off) * 2 * plane_bytes;
+        for (int p = tid; p < xw * xh; p += 256) {
+            const int hy = p / xw, hx = p - hy * xw;
+            const int yy = xy0 + hy, xx = xx0 + hx;
+            float v[8];
+            if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) {
+                g8_load8(base + ((size_t)(yy >> a.up) * a.ws + (xx >> a.up)) * 16, plane_bytes, v);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = 0.f;
+            }
+            xt[p] = make_float4(v[0], v[1], v[2], v[3]);
+            if (PLX > 1) xt[a.x_px + p] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+    __syncthreads();
+    // ---- stage A on the middle tile: columns of SM_RPT pixels, mw x ceil(mh / SM_RPT) of them ----
+    const int mgroups = (mh + SM_RPT - 1) / SM_RPT;
+    for (int t = tid; t < mw * mgroups; t += 256) {
+        const int col = t % mw, rg = t / mw;
+        float acc[SM_RPT][CMIDB];
+#pragma unroll
+        for (int j = 0; j < SM_RPT; ++j)
+#pragma unroll
+            for (int c = 0; c < CMIDB; ++c) acc[j][c] = 0.f;
+        small_column<CINB, CMIDB>(xt, xw, a.x_px, rg * SM_RPT, col, wla, a.kha, a.kwa, acc);
+#pragma unroll
+        for (int j = 0; j < SM_RPT; ++j) {
+            const int row = rg * SM_RPT + j;
+            if (row < mh) {
+                const int yy = my0 + row, xx = mx0 + col;
+                const bool in = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
+                float o[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    o[c] = (c < CMIDB && in) ? mpg::apply_act(acc[j][c < CMIDB ? c : 0] + (a.bias_a != nullptr ? a.bias_a[c] : 0.f), a.act_a, a.leak_a) : 0.f;
+                mt[row * mw + col] = make_float4(o[0], o[1], o[2], o[3]);
+                if (PLM > 1) mt[a.mid_px + row * mw + col] = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage B + shortcut on the output tile ----
+    const int lx = tid % SM_TW, yg = tid / SM_TW;
+    float acc[SM_RPT][COUTB];
+#pragma unroll
+    for (int j = 0; j < SM_RPT; ++j)
+#pragma unroll
+        for (int c = 0; c < COUTB; ++c) acc[j][c] = 0.f;
+    small_column<CMIDB, COUTB>(mt, mw, a.mid_px, yg * SM_RPT, lx, wlb, a.khb, a.kwb, acc);
+    if (a.wsc != nullptr)     // the shortcut reads the input tile; its first tap sits at (ptb + pta - pts, plb + pla - pls) of it
+        small_column<CINB, COUTB>(xt, xw, a.x_px, yg * SM_RPT + a.ptb + a.pta - a.pts, lx + a.plb + a.pla - a.pls, wls, a.khs, a.kws, acc);
+    const int x = x0 + lx;
+    if (x >= a.w) return;
+    const size_t plane_px = (size_t)a.h * a.w;
+#pragma unroll
+    for (int j = 0; j < SM_RPT; ++j) {
+        const int y = y0 + yg * SM_RPT + j;
+        if (y >= a.h) break;
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            o[q] = (q < COUTB && q < a.cout) ? mpg::apply_act(acc[j][q < COUTB ? q : 0] + (a.bias_b != nullptr ? a.bias_b[q] : 0.f), a.act_b, a.leak_b) : 0.f;
         const size_t pix = (size_t)y * a.w + x;
         if (a.y != nullptr) {
             float* dst = a.y + ((size_t)b * plane_px + pix) * a.cout;
@@ -1314,7 +1575,7 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
 
 // ---- MPG_PREC_F16F6 shapes (host mirror of Pipe6<NT>) ----
 bool f6_supported(int nt) { return nt >= 1 && nt <= 4; }
-int f6_waves(int nt) { return nt == 1 ? 4 : 8; }
+int f6_waves(int nt) { return (nt == 1 || (nt == 4 && MPG_W4)) ? 4 : 8; }
 
 SegShape seg_shape_f6(int kh, int kw, int cin, int nt) {
     // nchunks = channel groups (one LDS halo image each), sc = weight stages of the whole segment
@@ -1520,6 +1781,73 @@ extern "C" int mpg_conv_pack_weights(mpg_stream_t stream, const float* w_hwio, i
                            kh * kw, w_cin_total, w_c_off, cin, cout, wscale, cout_scale,
                            (float*)((char*)out + pack_base_bytes(kh, kw, cin, cout, prec)));
     MPG_LAUNCH_CHECK("pack_weights_kernel");
+}
+
+// One residual block of <= 8-channel convolutions as a single launch (conv_small_pair_kernel).
+template <int CI, int CM, int CO>
+static hipError_t launch_pair(dim3 grid, size_t lds, hipStream_t st, const PairArgs& a) {
+    static int lds_limit[64] = {0};
+    if (lds > 48 * 1024) {
+        hipError_t e = mpg::ensure_dyn_lds(reinterpret_cast<const void*>(&conv_small_pair_kernel<CI, CM, CO>), (int)lds, lds_limit);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((conv_small_pair_kernel<CI, CM, CO>), grid, dim3(256), lds, st, a);
+    return hipSuccess;
+}
+
+extern "C" int mpg_conv2d_small_pair(mpg_stream_t stream, const mpg_small_pair_desc* d) {
+    MPG_REQUIRE(d != nullptr, "mpg_conv2d_small_pair: null desc");
+    MPG_REQUIRE(d->n >= 1 && d->h >= 1 && d->w >= 1 && d->n <= 65535, "mpg_conv2d_small_pair: bad shape %d x %d x %d", d->n, d->h, d->w);
+    MPG_REQUIRE(d->cin >= 1 && d->cin <= 8 && d->cmid >= 1 && d->cmid <= 8 && d->cout >= 1 && d->cout <= 8,
+                "mpg_conv2d_small_pair: %d -> %d -> %d channels (1..8 each)", d->cin, d->cmid, d->cout);
+    MPG_REQUIRE(d->x && d->wpack_a && d->wpack_b, "mpg_conv2d_small_pair: null pointer");
+    MPG_REQUIRE(d->y != nullptr || d->y_g8 != nullptr, "mpg_conv2d_small_pair: no output requested");
+    MPG_REQUIRE(d->kh_a >= 1 && d->kh_a <= 7 && d->kw_a >= 1 && d->kw_a <= 7 && d->kh_b >= 1 && d->kh_b <= 7 && d->kw_b >= 1 && d->kw_b <= 7,
+                "mpg_conv2d_small_pair: kernel sizes 1..7");
+    MPG_REQUIRE((d->kh_a & 1) && (d->kw_a & 1) && (d->kh_b & 1) && (d->kw_b & 1), "mpg_conv2d_small_pair: odd filters only");
+    MPG_REQUIRE(d->wpack_s == nullptr || (d->kh_s >= 1 && d->kh_s <= d->kh_a + d->kh_b - 1 && d->kw_s >= 1 && d->kw_s <= d->kw_a + d->kw_b - 1 &&
+                                          (d->kh_s & 1) && (d->kw_s & 1) && ((d->kh_a + d->kh_b) & 1) == 0 && ((d->kw_a + d->kw_b) & 1) == 0),
+                "mpg_conv2d_small_pair: the shortcut filter must be odd and fit inside the input tile of two odd filters");
+    MPG_REQUIRE(d->g_off >= 0 && d->g_off < d->cgroups, "mpg_conv2d_small_pair: channel-group range");
+    MPG_REQUIRE(d->up_log2 >= 0 && d->up_log2 <= 4 && (d->h % (1 << d->up_log2)) == 0 && (d->w % (1 << d->up_log2)) == 0,
+                "mpg_conv2d_small_pair: upsample %d", d->up_log2);
+    MPG_REQUIRE(d->act_a >= MPG_ACT_NONE && d->act_a <= MPG_ACT_TANH && d->act_b >= MPG_ACT_NONE && d->act_b <= MPG_ACT_TANH, "mpg_conv2d_small_pair: bad act");
+    MPG_REQUIRE(d->prec == MPG_PREC_F16X1 || d->prec == MPG_PREC_F16X3 || d->prec == MPG_PREC_F16F6, "mpg_conv2d_small_pair: bad prec %d", d->prec);
+    MPG_REQUIRE((((uintptr_t)d->x) & 15) == 0 && (((uintptr_t)d->y_g8) & 15) == 0, "mpg_conv2d_small_pair: misaligned tensor");
+    PairArgs a;
+    a.n = d->n; a.h = d->h; a.w = d->w;
+    a.x = (const char*)d->x; a.cg_total = d->cgroups; a.g_off = d->g_off; a.up = d->up_log2;
+    a.hs = d->h >> d->up_log2; a.ws = d->w >> d->up_log2;
+    a.wa = (const float*)((const char*)d->wpack_a + pack_base_bytes(d->kh_a, d->kw_a, d->cin, d->cmid, d->prec));
+    a.wb = (const float*)((const char*)d->wpack_b + pack_base_bytes(d->kh_b, d->kw_b, d->cmid, d->cout, d->prec));
+    a.wsc = d->wpack_s ? (const float*)((const char*)d->wpack_s + pack_base_bytes(d->kh_s, d->kw_s, d->cin, d->cout, d->prec)) : nullptr;
+    a.kha = d->kh_a; a.kwa = d->kw_a; a.pta = (d->kh_a - 1) / 2; a.pla = (d->kw_a - 1) / 2;
+    a.khb = d->kh_b; a.kwb = d->kw_b; a.ptb = (d->kh_b - 1) / 2; a.plb = (d->kw_b - 1) / 2;
+    a.khs = d->wpack_s ? d->kh_s : 1; a.kws = d->wpack_s ? d->kw_s : 1; a.pts = (a.khs - 1) / 2; a.pls = (a.kws - 1) / 2;
+    a.bias_a = d->bias_a; a.bias_b = d->bias_b; a.act_a = d->act_a; a.act_b = d->act_b; a.leak_a = d->leak_a; a.leak_b = d->leak_b;
+    a.cout = d->cout; a.y = d->y; a.y_g8 = (char*)d->y_g8;
+    const int mw = SM_TW + a.kwb - 1, mh = SM_TH + a.khb - 1;
+    const int mgroups = (mh + SM_RPT - 1) / SM_RPT;
+    const int xw = mw + a.kwa - 1, xh = mgroups * SM_RPT + a.kha - 1;      // rows past the middle tile are read, never used
+    a.x_px = xw * xh;
+    a.mid_px = mw * (mgroups * SM_RPT + a.khb - 1);
+    // compile-time channel bounds: cin in {1, 4, 8}, cmid in {2, 8}, cout in {1, 8}
+    const int ci = d->cin == 1 ? 1 : d->cin <= 4 ? 4 : 8, cm = d->cmid <= 2 ? 2 : 8, co = d->cout == 1 ? 1 : 8;
+    const size_t lds = ((size_t)((ci + 3) / 4) * a.x_px + (size_t)((cm + 3) / 4) * a.mid_px) * 16 +
+                       ((size_t)a.kha * a.kwa * ci * cm + (size_t)a.khb * a.kwb * cm * co + (size_t)a.khs * a.kws * ci * co) * sizeof(float);
+    MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_small_pair: LDS budget %zu exceeds 160 KiB", lds);
+    const dim3 grid((unsigned)((d->w + SM_TW - 1) / SM_TW), (unsigned)((d->h + SM_TH - 1) / SM_TH), (unsigned)d->n);
+    hipError_t le = hipSuccess;
+    switch (ci * 100 + cm * 10 + co) {
+#define MPG_PAIR(CI, CM, CO) case CI * 100 + CM * 10 + CO: le = launch_pair<CI, CM, CO>(grid, lds, (hipStream_t)stream, a); break;
+        MPG_PAIR(1, 2, 1) MPG_PAIR(1, 2, 8) MPG_PAIR(1, 8, 1) MPG_PAIR(1, 8, 8)
+        MPG_PAIR(4, 2, 1) MPG_PAIR(4, 2, 8) MPG_PAIR(4, 8, 1) MPG_PAIR(4, 8, 8)
+        MPG_PAIR(8, 2, 1) MPG_PAIR(8, 2, 8) MPG_PAIR(8, 8, 1) MPG_PAIR(8, 8, 8)
+#undef MPG_PAIR
+        default: break;
+    }
+    if (le != hipSuccess) return mpg::hip_check(le, "mpg_conv2d_small_pair: hipFuncSetAttribute(dynamic LDS)");
+    MPG_LAUNCH_CHECK("conv_small_pair_kernel");
 }
 
 #if MPG_DIAG_SMALL

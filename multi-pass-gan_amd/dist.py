@@ -79,6 +79,30 @@ class Comm(object):
                                    async_op=True)
         return _Gathered(full, work, keep=local)
 
+    def all_to_all_blocks_start(self, local, dim):
+        """The other way to hand a pass's output to the next pass: rank r holds the slab [S/R, ...] of a
+        volume along axis 0 and the next pass needs, on rank r, the volume's range r along axis `dim` (its own slice
+        axis) -- but ALL of axis 0.  Every rank sends rank q the block `local[..., range q along dim, ...]` and receives
+        R blocks of S^3/R^2 elements: 1/R of the bytes an all-gather moves.  Returns a handle whose wait() gives
+        [S, ...] with axis `dim` cut to this rank's range (block q at rows [q S/R, (q+1) S/R))."""
+        if self.world == 1:
+            return _Gathered(local, None)
+        r = self.world
+        if dim < 1 or dim >= local.dim() or local.shape[dim] % r:
+            raise ValueError("all_to_all_blocks: axis %d of %s does not divide over %d ranks" % (dim, tuple(local.shape), r))
+        per = local.shape[dim] // r
+        shp = list(local.shape)
+        # [p, .., R, per, ..] -> [R, p, .., per, ..]: block q is contiguous
+        send = local.reshape(shp[:dim] + [r, per] + shp[dim + 1:]).movedim(dim, 0).contiguous()
+        recv = torch.empty_like(send)
+        # one flat buffer each way (equal splits); gloo implements this form too (the CPU rehearsal)
+        work = dist.all_to_all_single(recv, send, group=self._data_group(local) if local.is_cuda else self.group, async_op=True)
+        out_shape = [r * shp[0]] + shp[1:dim] + [per] + shp[dim + 1:]
+        return _Gathered(recv.reshape(out_shape), work, keep=send)
+
+    def all_to_all_blocks(self, local, dim):
+        return self.all_to_all_blocks_start(local, dim).wait()
+
     def all_reduce_mean(self, flat):
         """data-parallel training: average one flat gradient buffer (one bucket per optimiser) in place"""
         if self.world == 1:

@@ -160,7 +160,7 @@ def random_normal_like(x, channels, stddev, seed=0):
     every run; `seed` selects the stream (the reference draws from TensorFlow's global generator)"""
     shape = list(x.shape)
     shape[-1] = int(channels)
-    return Node("random_normal", [x], shape=shape, stddev=float(stddev), seed=int(seed))
+    return Node("random_normal", [x], shape=shape, stddev=float(stddev), seed=None if seed is None else int(seed))
 
 
 def slice_channels(x, begin, size):

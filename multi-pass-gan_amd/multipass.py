@@ -31,6 +31,41 @@ class LocalComm(object):
         return local
 
 
+EXCHANGES = ("all_gather", "all_to_all")
+
+
+def _check_exchange(exchange):
+    if exchange not in EXCHANGES:
+        raise ValueError("exchange %r: expected one of %s" % (exchange, EXCHANGES))
+    return exchange == "all_to_all"
+
+
+def _hand_over(comm, out, s, perm, a2a, backend):
+    """Pass p produced `out` = this rank's slab [S/R, S, S] of a volume V; pass p+1 slices Y = transpose(V, perm) along
+    its axis 0 and this rank evaluates Y[lo:hi].  Returns (Y_local, V_full or None):
+    all-gather: every rank receives all of V (S^3 elements) and keeps its rows of the transposed volume;
+    all-to-all: only the [S/R, S, S/R] blocks that end up in Y[lo:hi] travel (S^3 / R elements per rank), V is never whole.
+    (multipassGAN-out.py:459,521; multipassGAN-4x.py:1113)"""
+    return _finish_hand_over(_start_hand_over(comm, out, s, perm, a2a), backend)
+
+
+def _start_hand_over(comm, out, s, perm, a2a):
+    if a2a and comm.world > 1 and perm[0] != 0:
+        return ("a2a", comm.all_to_all_blocks_start(out, perm[0]), comm, s, perm)
+    return ("gather", _start_gather(comm, out, s), comm, s, perm)
+
+
+def _finish_hand_over(h, backend):
+    kind, handle, comm, s, perm = h
+    lo, hi = slice_range(s, comm)
+    if kind == "a2a":
+        part = handle.wait()                                   # [S, .., S/R, ..]: all of axis 0, this rank's range of axis perm[0]
+        return backend.volume_transpose(part, perm), None
+    full = handle.wait()
+    y = backend.volume_transpose(full, perm) if tuple(perm) != (0, 1, 2) else full
+    return y[lo:hi], full
+
+
 def slice_range(total, comm):
     """contiguous slice range of this rank; ``total`` must divide by the world size"""
     if total % comm.world:
@@ -175,9 +210,9 @@ def _start_gather(comm, local, total):
     return _Now(comm.all_gather_slabs(local, total))
 
 
-def _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale):
+def _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale, a2a=False):
     """pass 1 of one volume: upsamplingMode 2 -- zoom z, slices along z (4x.py:1103,1126-1133); the
-    all-gather of the slabs is started, not awaited"""
+    hand-over of the slabs to pass 2 is started, not awaited"""
     nch = low.shape[3]
     s = low.shape[0] * up_res
     low1 = low
@@ -188,27 +223,29 @@ def _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale):
     lo, hi = slice_range(s, comm)
     out1 = _run_pass(gen1, xs, None, lo, hi, batch)                  # [hi-lo, s, s] = (z, y, x)
     out1 = backend.cutoff(out1, CUTOFF)                              # 4x.py:1156-1157
-    return _start_gather(comm, out1, s)
+    return _start_hand_over(comm, out1, s, (2, 0, 1), a2a)
 
 
-def _pass2_4x(gen2, low, v1, up_res, batch, comm, backend, vel_scale):
-    """pass 2: upsamplingMode 1 -- slices along x of (z, y) planes (4x.py:1113-1119)"""
+def _pass2_4x(gen2, low, hand, up_res, batch, comm, backend, vel_scale):
+    """pass 2: upsamplingMode 1 -- slices along x of (z, y) planes (4x.py:1113-1119).  `hand`: the started hand-over of
+    pass 1's volume (_start_hand_over with perm (2, 0, 1)).  Returns (started all-gather of the output, v1 or None)."""
     nch = low.shape[3]
     s = low.shape[0] * up_res
     lo, hi = slice_range(s, comm)
+    ys, v1 = _finish_hand_over(hand, backend)                        # [hi-lo][z][y]: this rank's x planes of pass 1
     if nch > 1:
         vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
         if vel_scale != 1.0:
             vel[..., 1:3] *= vel_scale                               # 4x.py:283 on the 3-channel array: vy,vz only
         for ax in range(3):                                          # 4x.py:1095
             vel = backend.axis_zoom_linear(vel, ax, up_res)
-        vol = torch.cat([v1.reshape(s, s, s, 1), vel], dim=3)
-        # transpose(0,3,1,2,4) then the two channel swaps (d,vx,vy,vz) -> (d,vy,vz,vx)
-        xin = backend.volume_transpose(vol, (2, 0, 1), chan_map=[0, 2, 3, 1])
+        # transpose(0,3,1,2,4) then the two channel swaps (d,vx,vy,vz) -> (d,vy,vz,vx); only this rank's x range
+        velx = backend.volume_transpose(vel[:, :, lo:hi].contiguous(), (2, 0, 1), chan_map=[1, 2, 0])
+        xin = torch.cat([ys.reshape(hi - lo, s, s, 1), velx], dim=3)
     else:
-        xin = backend.volume_transpose(v1, (2, 0, 1)).reshape(s, s, s, 1)
-    out2 = _run_pass(gen2, xin, None, lo, hi, batch)                 # [x-range][z][y]
-    return _start_gather(comm, out2, s)
+        xin = ys.reshape(hi - lo, s, s, 1)
+    out2 = _run_pass(gen2, xin, None, 0, hi - lo, batch)             # [x-range][z][y]
+    return _start_gather(comm, out2, s), v1
 
 
 def refine_pass_4x(gen, low, prev, up_res=4, mode=1, batch=8, comm=None, backend=ops, vel_scale=1.0, apply_cutoff=True):
@@ -235,30 +272,30 @@ def refine_pass_4x(gen, low, prev, up_res=4, mode=1, batch=8, comm=None, backend
     return backend.volume_transpose(vol, back, cutoff=CUTOFF if apply_cutoff else 0.0)
 
 
-def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0):
+def two_pass_4x(gen1, gen2, low, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0, exchange="all_gather"):
     """low: device [z,y,x,C].  Returns (final [z,y,x], pass-1 volume [z,y,x]), both with the
-    <5e-4 cutoff of the files the reference writes between and after the passes."""
+    <5e-4 cutoff of the files the reference writes between and after the passes.  exchange: how pass 1's slabs reach
+    pass 2 on several ranks ("all_gather": the whole volume to every rank; "all_to_all": only the blocks each rank's
+    planes need -- the pass-1 volume is then never assembled and the second result is None)."""
     comm = comm or LocalComm()
-    v1 = _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale).wait()         # [z, y, x]
-    full2 = _pass2_4x(gen2, low, v1, up_res, batch, comm, backend, vel_scale).wait()  # [x, z, y]
-    final = backend.volume_transpose(full2, (1, 2, 0), cutoff=CUTOFF)   # 4x.py:1142,1156
+    hand = _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale, _check_exchange(exchange))
+    g2, v1 = _pass2_4x(gen2, low, hand, up_res, batch, comm, backend, vel_scale)
+    final = backend.volume_transpose(g2.wait(), (1, 2, 0), cutoff=CUTOFF)   # [x, z, y] -> [z, y, x]: 4x.py:1142,1156
     return final, v1
 
 
-def _two_pass_4x_steps(gen1, gen2, lows, finals, where, up_res, batch, comm, backend, vel_scale):
+def _two_pass_4x_steps(gen1, gen2, lows, finals, where, up_res, batch, comm, backend, vel_scale, a2a=False):
     """generator over the software pipeline of two_pass_4x_batch: step i issues pass 1 of volume i, pass 2 of volume
     i-1 and the final transpose of volume i-2; finals[where[k]] receives volume k"""
     n = len(lows)
     g1, g2 = [None] * n, [None] * n
     for i in range(n + 2):
         if i < n:
-            g1[i] = _pass1_4x(gen1, lows[i], up_res, batch, comm, backend, vel_scale)
+            g1[i] = _pass1_4x(gen1, lows[i], up_res, batch, comm, backend, vel_scale, a2a)
         j = i - 1
         if 0 <= j < n:
-            v1 = g1[j].wait()
+            g2[j], _ = _pass2_4x(gen2, lows[j], g1[j], up_res, batch, comm, backend, vel_scale)
             g1[j] = None
-            g2[j] = _pass2_4x(gen2, lows[j], v1, up_res, batch, comm, backend, vel_scale)
-            del v1
         k = i - 2
         if 0 <= k < n:
             finals[where[k]] = backend.volume_transpose(g2[k].wait(), (1, 2, 0), cutoff=CUTOFF)
@@ -266,7 +303,8 @@ def _two_pass_4x_steps(gen1, gen2, lows, finals, where, up_res, batch, comm, bac
         yield
 
 
-def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0, lanes=None):
+def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=ops, vel_scale=1.0, lanes=None,
+                      exchange="all_gather"):
     """The same two passes over a list of independent volumes, software-pipelined by one volume so that the
     slab exchange of volume i (RCCL all-gather on its own stream) runs under pass 1 of volume i+1 and
     pass 2 of volume i-1.  Same results as calling two_pass_4x per volume.  Returns the final volumes.
@@ -275,11 +313,12 @@ def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=op
     round-robin to 1 + len(lanes) lanes, each issuing its pipeline on its own HIP stream, so that the launch tails and
     the latency-bound small layers of one lane run under the matrix-bound layers of another."""
     comm = comm or LocalComm()
+    a2a = _check_exchange(exchange)
     n = len(lows)
     finals = [None] * n
     pairs = [(gen1, gen2)] + list(lanes or [])
     if len(pairs) == 1 or n < 2 or not lows[0].is_cuda:
-        for _ in _two_pass_4x_steps(gen1, gen2, lows, finals, list(range(n)), up_res, batch, comm, backend, vel_scale):
+        for _ in _two_pass_4x_steps(gen1, gen2, lows, finals, list(range(n)), up_res, batch, comm, backend, vel_scale, a2a):
             pass
         return finals
     cur = torch.cuda.current_stream()
@@ -291,7 +330,7 @@ def two_pass_4x_batch(gen1, gen2, lows, up_res=4, batch=8, comm=None, backend=op
         st = _lane_stream(li)
         st.wait_stream(cur)
         its.append((st, _two_pass_4x_steps(ga, gb, [lows[i] for i in idx], finals, idx, up_res, batch, comm, backend,
-                                           vel_scale)))
+                                           vel_scale, a2a)))
     live = list(its)
     _NESTED[0] = True
     try:
@@ -354,11 +393,13 @@ def slice_batch_8x(low, up_res, pass_no, transpose_axis, backend=ops):
     return xs.reshape(-1, sim, sim, nch)
 
 
-def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops, apply_cutoff=True, transpose_axis=0):
+def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops, apply_cutoff=True, transpose_axis=0,
+                 exchange="all_gather"):
     """gens: 1..3 Generator objects (first one firstGen).  low: device [z,y,x,4] with velocities
     already scaled by velScale (out.py:138).  Returns the density volume after the reference's final
     axis restore (:587-590): [z,y,x] for transposeAxis 0."""
     comm = comm or LocalComm()
+    a2a = _check_exchange(exchange)
     sim = low.shape[0]
     s = sim * up_res
     lo, hi = slice_range(s, comm)
@@ -369,19 +410,17 @@ def multipass_8x(gens, low, up_res=8, batches=(8, 2, 2), comm=None, backend=ops,
         out = _run_pass(gens[0], xs_r, None, 0, hi - lo, batches[0])
     else:
         out = _run_pass(gens[0], xs, None, lo, hi, batches[0])
-    vol = comm.all_gather_slabs(out, s)
     if len(gens) > 1:
         # pass 2 (463-523): conditioned on planes of dim_output.transpose(2,1,0) (:459)
-        ys = backend.volume_transpose(vol, (2, 1, 0))
+        ys, _ = _hand_over(comm, out, s, (2, 1, 0), a2a, backend)
         xl = slice_batch_8x(low, up_res, 2, transpose_axis, backend)
-        out = _run_pass(gens[1], xl, ys, lo, hi, batches[1])
-        vol = comm.all_gather_slabs(out, s)
+        out = _run_pass(gens[1], xl[lo:hi], ys, 0, hi - lo, batches[1])
     if len(gens) > 2:
         # pass 3 (525-585): conditioned on the previous result .transpose(1,2,0) (:521)
-        ys = backend.volume_transpose(vol, (1, 2, 0))
+        ys, _ = _hand_over(comm, out, s, (1, 2, 0), a2a, backend)
         xl = slice_batch_8x(low, up_res, 3, transpose_axis, backend)
-        out = _run_pass(gens[2], xl, ys, lo, hi, batches[2])
-        vol = comm.all_gather_slabs(out, s)
+        out = _run_pass(gens[2], xl[lo:hi], ys, 0, hi - lo, batches[2])
+    vol = comm.all_gather_slabs(out, s)
     # the transposes the reference applies to its last dim_output, composed (459 / 521 / 583, then 587-590)
     perm = {1: (0, 1, 2), 2: (2, 1, 0), 3: (1, 0, 2)}[len(gens)]
     thr = CUTOFF if apply_cutoff else 0.0

@@ -229,6 +229,63 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
     return outs[0] if len(outs) == 1 else tuple(outs)
 
 
+def small_pair_ok(cin, cmid, cout, ka, kb, ks=None):
+    """shapes mpg_conv2d_small_pair takes: <= 8 channels everywhere, odd filters up to 7x7, shortcut inside the input tile"""
+    if not (1 <= cin <= 8 and 1 <= cmid <= 8 and 1 <= cout <= 8):
+        return False
+    for k in (ka, kb) + ((ks,) if ks is not None else ()):
+        if k[0] % 2 == 0 or k[1] % 2 == 0 or max(k) > 7:
+            return False
+    return ks is None or (ks[0] <= ka[0] + kb[0] - 1 and ks[1] <= ka[1] + kb[1] - 1)
+
+
+def conv2d_small_pair(x, c_off, up_log2, pk_a, pk_b, pk_s, out_hw, bias_a=None, act_a=None, leak_a=0.2, bias_b=None,
+                      act_b=None, leak_b=0.2, want_f32=True, want_g8=False):
+    """y = act_b(conv_b(act_a(conv_a(up(x)) + bias_a)) + conv_s(up(x)) + bias_b): a residual block of <= 8-channel
+    convolutions as one launch (mpg_conv2d_small_pair); x: G8 (or fp32 NHWC, converted), pk_*: PackedWeights."""
+    lib = _lib.load()
+    if isinstance(x, torch.Tensor):
+        x = to_g8(x, c_off, pk_a.cin)
+        c_off = 0
+    if c_off % 8:
+        raise _lib.MpgError("conv2d_small_pair: channel offset %d of a G8 source is not a multiple of 8" % c_off)
+    h, w = out_hw
+    if x.h << up_log2 != h or x.w << up_log2 != w:
+        raise _lib.MpgError("conv2d_small_pair: input %dx%d does not match output %dx%d (up 2^%d)" % (x.h, x.w, h, w, up_log2))
+    if pk_b.cin != pk_a.cout or (pk_s is not None and (pk_s.cin != pk_a.cin or pk_s.cout != pk_b.cout)):
+        raise _lib.MpgError("conv2d_small_pair: channel counts of the three convolutions do not chain")
+    if len(set(p.prec for p in (pk_a, pk_b) + ((pk_s,) if pk_s is not None else ()))) != 1:
+        raise _lib.MpgError("conv2d_small_pair: weights packed for different precisions")
+    if c_off + pk_a.cin > x.c:
+        raise _lib.MpgError("conv2d_small_pair: channel window exceeds the input")
+    dev = x.buf.device
+    d = _lib.SmallPairDesc()
+    d.n, d.h, d.w = x.n, h, w
+    d.x, d.cin, d.cgroups, d.g_off, d.up_log2 = x.buf.data_ptr(), pk_a.cin, x.groups, c_off // 8, up_log2
+    d.wpack_a, d.kh_a, d.kw_a, d.cmid = pk_a.buf.data_ptr(), pk_a.kh, pk_a.kw, pk_a.cout
+    d.wpack_b, d.kh_b, d.kw_b, d.cout = pk_b.buf.data_ptr(), pk_b.kh, pk_b.kw, pk_b.cout
+    if pk_s is not None:
+        d.wpack_s, d.kh_s, d.kw_s = pk_s.buf.data_ptr(), pk_s.kh, pk_s.kw
+    if bias_a is not None:
+        d.bias_a = _dev(bias_a, "bias_a").data_ptr()
+    if bias_b is not None:
+        d.bias_b = _dev(bias_b, "bias_b").data_ptr()
+    d.act_a, d.leak_a, d.act_b, d.leak_b = _lib.act_id(act_a), leak_a, _lib.act_id(act_b), leak_b
+    d.prec = pk_a.prec
+    y = y8 = None
+    if want_f32:
+        y = torch.empty((x.n, h, w, pk_b.cout), dtype=torch.float32, device=dev)
+        d.y = y.data_ptr()
+    if want_g8:
+        y8 = G8.empty(x.n, h, w, pk_b.cout, dev, G8_F16)
+        d.y_g8 = y8.buf.data_ptr()
+    outs = [o for o in (y, y8) if o is not None]
+    if not outs:
+        raise _lib.MpgError("conv2d_small_pair: no output requested")
+    _lib.check(lib.mpg_conv2d_small_pair(_stream(), ctypes.byref(d)), "mpg_conv2d_small_pair")
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
 def conv2d_direct(x, w_hwio, stride=(1, 1), wscale=1.0, cout_scale=None, bias=None, act=None, leak=0.2):
     """fp32 vector-ALU convolution, any stride (tf.nn.conv2d SAME, GAN.py:686-691)."""
     lib = _lib.load()

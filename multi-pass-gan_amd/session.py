@@ -245,6 +245,8 @@ class Session(object):
                 plan.last_use[d.id] = idx
 
         emit(fetch)
+        self._fuse_small_pairs(plan, fused_steps, consumers, fetch)
+        fused_steps = [(n, fn) for n, fn in fused_steps if fn.info.get("kind") != "fused_into_next"]
         fused_ids = set(n.id for n, _ in fused_steps)
         for n, fn in fused_steps:
             fl = ops.flavour_for(fn.info["prec"])
@@ -266,6 +268,77 @@ class Session(object):
             if nid not in keep:
                 plan.free_after[idx].append(nid)
         return plan
+
+    # ---- residual blocks of small-channel convolutions: two launches -> one -------------------------------
+    def _fuse_small_pairs(self, plan, fused_steps, consumers, fetch):
+        """relu(convB(relu(convA(x))) + conv1x1(x)) with <= 8 channels everywhere (resBlock 0 and 3 of gen_resnet,
+        multipassGAN-4x.py:505-526,560,564) was planned as two conv_small launches with the middle tensor going through
+        HBM; here launch A is dropped and launch B replaced by one mpg_conv2d_small_pair call."""
+        by_id = dict((n.id, (n, fn)) for n, fn in fused_steps)
+        index = dict((n.id, i) for i, (n, _) in enumerate(plan.steps))
+        for n2, fn2 in list(fused_steps):
+            p2 = getattr(fn2, "parts", None)
+            if p2 is None or p2["pn"] or p2["post_add"] is not None or p2["cout"] > 8 or not 1 <= len(p2["segs"]) <= 2:
+                continue
+            src1, c_off1, up1, term_b, w_off_b, cin_b = p2["segs"][0]
+            if src1.id not in by_id or c_off1 != 0 or up1 != 0 or w_off_b != 0:
+                continue
+            n1, fn1 = by_id[src1.id]
+            p1 = getattr(fn1, "parts", None)
+            if (p1 is None or n1 is fetch or len(consumers.get(n1.id, [])) != 1 or p1["pn"] or p1["post_add"] is not None
+                    or len(p1["segs"]) != 1 or p1["prec"] != p2["prec"] or p1["cout"] != cin_b):
+                continue
+            src0, c_off0, up0, term_a, w_off_a, cin_a = p1["segs"][0]
+            if w_off_a != 0 or cin_a != term_a.conv.inputs[1].shape[2] or cin_b != term_b.conv.inputs[1].shape[2]:
+                continue
+            term_s = None
+            if len(p2["segs"]) == 2:
+                src_s, c_off_s, up_s, term_s, w_off_s, cin_s = p2["segs"][1]
+                if src_s is not src0 or c_off_s != c_off0 or up_s != up0 or w_off_s != 0 or cin_s != cin_a:
+                    continue
+            ka, kb = tuple(term_a.conv.inputs[1].shape[:2]), tuple(term_b.conv.inputs[1].shape[:2])
+            ks = tuple(term_s.conv.inputs[1].shape[:2]) if term_s is not None else None
+            if not ops.small_pair_ok(cin_a, p1["cout"], p2["cout"], ka, kb, ks):
+                continue
+            emit2 = fn2.emit
+
+            def run(env, src0=src0, c_off0=c_off0, up0=up0, cin_a=cin_a, term_a=term_a, term_b=term_b, term_s=term_s,
+                    p1=p1, p2=p2, emit2=emit2):
+                prec = p2["prec"]
+                pk_a = self._packed_for(term_a, 0, cin_a, prec)
+                pk_b = self._packed_for(term_b, 0, p1["cout"], prec)
+                pk_s = self._packed_for(term_s, 0, cin_a, prec) if term_s is not None else None
+                g8, off = self._g8(env, src0, c_off0, cin_a, ops.G8_F16)
+                res = ops.conv2d_small_pair(g8, off, up0, pk_a, pk_b, pk_s, p2["out_hw"], bias_a=self._bias_for(p1["terms"]),
+                                            act_a=p1["act"], leak_a=p1["leak"], bias_b=self._bias_for(p2["terms"]),
+                                            act_b=p2["act"], leak_b=p2["leak"], want_f32=emit2["f32"], want_g8=emit2["g8"])
+                res = list(res) if isinstance(res, tuple) else [res]
+                out = {"f32": None, "g8": {}}
+                if emit2["f32"]:
+                    out["f32"] = res.pop(0)
+                if emit2["g8"]:
+                    out["g8"][ops.G8_F16] = res.pop(0)
+                return out
+
+            run.emit = emit2
+            run.parts = None
+            run.info = dict(fn2.info)
+            run.info["kind"] = "conv2d_small_pair"
+            run.info["cmid"] = p1["cout"]
+            run.info["segments"] = [dict(fn1.info["segments"][0], role="conv_a")] + [
+                dict(sg, role="shortcut") for sg in fn2.info["segments"][1:]]
+            run.info["act_a"] = p1["act"]
+
+            def skipped(env):
+                return None
+            skipped.info = {"kind": "fused_into_next"}
+            plan.steps[index[n1.id]] = (n1, skipped)
+            plan.steps[index[n2.id]] = (n2, run)
+            # the block input is now read by the second launch
+            plan.last_use[src0.id] = max(plan.last_use.get(src0.id, 0), index[n2.id])
+            fused_steps[fused_steps.index((n1, fn1))] = (n1, skipped)
+            fused_steps[fused_steps.index((n2, fn2))] = (n2, run)
+            del by_id[n1.id]
 
     # ---- pattern matching -------------------------------------------------
     def _match_term(self, n, single_use):
@@ -375,6 +448,7 @@ class Session(object):
             return out
 
         run.emit = emit
+        run.parts = dict(segs=segs, terms=terms, act=act, leak=leak, pn=pn, post_add=post_add, prec=prec, cout=cout, out_hw=out_hw)
         run.info = {
             "kind": "conv2d_fused", "cout": cout, "act": act, "pixel_norm": pn, "prec": prec,
             "post_add": post_add.name if post_add is not None else None,
@@ -394,6 +468,8 @@ class Session(object):
             if node.op in ("variable", "placeholder"):
                 continue
             info = dict(getattr(fn, "info", {"kind": node.op}))
+            if info.get("kind") == "fused_into_next":
+                continue
             info["node"] = node.name
             if hasattr(fn, "emit"):
                 info["emit"] = dict(fn.emit)
@@ -549,7 +625,8 @@ class Session(object):
                 ref = self._f32(env, x)
                 gen = self.__dict__.setdefault("_noise_gen", {})
                 if n.id not in gen:
-                    gen[n.id] = torch.Generator(device=ref.device).manual_seed(1000003 * n.attrs["seed"] + 17)
+                    seed = n.attrs["seed"] if n.attrs["seed"] is not None else n.id        # one stream per noise node
+                    gen[n.id] = torch.Generator(device=ref.device).manual_seed(1000003 * seed + 17)
                 shape = tuple(ref.shape[:-1]) + (n.shape[-1],)
                 return torch.randn(shape, generator=gen[n.id], device=ref.device, dtype=torch.float32) * n.attrs["stddev"]
 

@@ -878,7 +878,7 @@ class Trainer4x(object):
     def __init__(self, tileSizeLow=16, upRes=4, n_inputChannels=4, batch_norm=True, upsampling_mode=2, device="cuda:0",
                  learning_rate=2e-4, beta1=0.5, lambda_l1=1.0, lambda2=0.0, lambda2_l=(1.0, 1.0, 1.0, 1.0),
                  weight_dld=1.0, bn_decay=0.999, variables=None, prec=ops.PREC_F16X3, seed=777, comm=None,
-                 use_tempo=False, lambda_t=1.0, adv_flag=True, clamping=True):
+                 use_tempo=False, lambda_t=1.0, adv_flag=True, clamping=True, lambda_t_l2=0.0):
         from . import arch
         from .session import VariableStore
         self.tileSizeLow, self.upRes, self.C = tileSizeLow, upRes, n_inputChannels
@@ -901,10 +901,14 @@ class Trainer4x(object):
         self.gen = arch.disc_binclass(self.x_disc, self.gen_part, reuse=True, **dkw)
         # temporal discriminator (multipassGAN-4x.py:790-885): three advected frames as channels
         self.use_tempo, self.kt, self.adv_flag, self.clamping, self.n_t = use_tempo, lambda_t, adv_flag, clamping, 3
-        if use_tempo:
+        # useTempoL2 (multipassGAN-4x.py:147-152,815-826): the l2 distance of consecutive advected generator frames
+        self.ktl = float(lambda_t_l2)
+        self.use_tempo_l2 = self.ktl > 1e-6
+        if use_tempo or self.use_tempo_l2:
             self.x_t = G.placeholder([None, self.n_input], name="x_t")
             self.gen_part_t = arch.gen_resnet(self.x_t, tileSizeLow, upRes, n_inputChannels, upsampling_mode=upsampling_mode,
                                               reuse=True, use_batch_norm=batch_norm, train=True)
+        if use_tempo:
             self.t_fake = G.placeholder([None, self.n_output * self.n_t], name="t_fake")
             self.t_real = G.placeholder([None, self.n_output * self.n_t], name="t_real")
             tk = dict(tileSizeLow=tileSizeLow, upRes=upRes, n_t_channels=self.n_t, use_batch_norm=batch_norm, train=True,
@@ -981,9 +985,20 @@ class Trainer4x(object):
         yts = torch.as_tensor(batch_yts, dtype=torch.float32, device=dev)
         gen_part_t = self.sess.run([self.gen_part_t], {self.x_t: xts})[0]
         fake = self._frames_as_channels(gen_part_t, batch_y_pos)
+        L = {}
+        if self.use_tempo_l2:
+            # tl_gen_loss = sum_i mean((frame_i - frame_i+1)^2) over the n_t advected generator frames (:821-826)
+            f = fake.reshape(-1, self.n_output, self.n_t)
+            fr = [f[:, :, i].contiguous() for i in range(self.n_t)]
+            tl = None
+            for i in range(self.n_t - 1):
+                term = PairLossFn.apply(fr[i], fr[i + 1], 1) / float(fr[i].numel())
+                tl = term if tl is None else tl + term
+            L["tl_gen_loss"] = tl
+        if not self.use_tempo:
+            return L
         real = self._frames_as_channels(yts, batch_y_pos)
         gen_t, disc_t = self.sess.run([self.gen_t, self.disc_t], {self.t_fake: fake, self.t_real: real})
-        L = {}
         L["t_disc_loss_disc"] = sigmoid_ce(disc_t, torch.ones_like(disc_t))
         L["t_disc_loss_gen"] = sigmoid_ce(gen_t, torch.zeros_like(gen_t))
         L["t_disc_loss"] = L["t_disc_loss_disc"] * self.weight_dld + L["t_disc_loss_gen"]
@@ -1001,7 +1016,10 @@ class Trainer4x(object):
         L = self.losses(batch_xs, batch_ys)
         Lt = self.tempo_losses(batch_xts, batch_yts, batch_y_pos)
         L.update(Lt)
-        L["gen_loss_complete"] = L["gen_loss_complete"] + self.kt * Lt["t_gen_loss"]
+        if self.use_tempo_l2:
+            L["gen_loss_complete"] = L["gen_loss_complete"] + self.ktl * Lt["tl_gen_loss"]      # :826
+        if self.use_tempo:
+            L["gen_loss_complete"] = L["gen_loss_complete"] + self.kt * Lt["t_gen_loss"]          # :866
         grads = torch.autograd.grad(L["gen_loss_complete"], self.opt_g.params, allow_unused=True)
         self.opt_g.step(grads, advance=advance)
         return L
@@ -1076,12 +1094,19 @@ class Trainer8x(object):
     def __init__(self, cfg, device="cuda:0", learning_rate=1e-4, beta1=0.0, beta2=0.99, lambda_l1=1.0, lambda2=0.0,
                  k2_ls=None, weight_dld=1.0, use_wgan_gp=True, use_LSGAN=False, variables=None,
                  prec=ops.PREC_F16X3, seed=777, comm=None, ema_decay=0.999, use_tempo=False, lambda_t=1.0,
-                 adv_flag=True, clamping=True, loss_scaling=False, adv_mode=0):
+                 adv_flag=True, clamping=True, loss_scaling=False, adv_mode=0, batch_norm=False):
         from . import arch
         from .session import VariableStore
         self.cfg = cfg
         self.k, self.k2, self.weight_dld = lambda_l1, lambda2, weight_dld
         self.use_wgan_gp, self.use_LSGAN = use_wgan_gp, use_LSGAN
+        # `batchNorm 1` / `use_mb_stddev 1` (multipassGAN-8x.py:85,149,847,907; both 0 in the reference runs): the kernels
+        # and their gradients exist, but the WGAN-GP penalty differentiates the critic twice and the second derivative of
+        # batch statistics / of the minibatch standard deviation is not built: LSGAN and sigmoid-CE losses only
+        if use_wgan_gp and (batch_norm or cfg.use_mb_stddev):
+            raise _lib.MpgError("batchNorm / use_mb_stddev with use_wgan_gp 1: the gradient penalty needs second derivatives "
+                                "of the batch statistics, which are not built -- train with use_wgan_gp 0")
+        self.batch_norm = bool(batch_norm)
         if use_wgan_gp:
             self.wgan_lambda, self.wgan_target, self.wgan_epsilon = (150.0, 30.0, 1e-3) if use_LSGAN else (10.0, 1.0, 1e-3)
         self.currentUpres = int(round(math.log(cfg.upRes, 2)))
@@ -1098,8 +1123,9 @@ class Trainer8x(object):
         else:       # later networks: `y` carries (target, previous pass) as two channels (:1041-1060)
             self.y2 = G.placeholder([None, cfg.n_output * 2], name="y")
             x_in, self.y_in = arch.later_network_input(self.x, self.y2, cfg)
-        self.gen_y = arch.growing_gen(x_in, cfg, self.percentage, train=True, currentUpres=self.currentUpres)
-        dk = dict(cfg=cfg, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
+        self.gen_y = arch.growing_gen(x_in, cfg, self.percentage, use_batch_norm=self.batch_norm, train=True,
+                                      currentUpres=self.currentUpres)
+        dk = dict(cfg=cfg, use_batch_norm=self.batch_norm, train=True, currentUpres=self.currentUpres)
         self.disc, self.f_y = arch.growing_disc(self.y_in, self.x_disc, self.percentage, reuse=False, **dk)
         self.gen, self.f_g = arch.growing_disc(self.gen_y, self.x_disc, self.percentage, reuse=True, **dk)
         self.d_out, _ = arch.growing_disc(self.y_gp, self.x_disc, self.percentage, reuse=True, **dk)
@@ -1119,9 +1145,9 @@ class Trainer8x(object):
             else:   # (:1171-1172) previous pass of the three frames = channel 1 of y_t
                 self.y_t2 = G.placeholder([None, cfg.n_output * 2], name="yt")
                 x_t_in, _ = arch.later_network_input(self.x_t, self.y_t2, cfg)
-            self.gen_ts = arch.growing_gen(x_t_in, cfg, self.percentage, reuse=True, train=True,
+            self.gen_ts = arch.growing_gen(x_t_in, cfg, self.percentage, reuse=True, use_batch_norm=self.batch_norm, train=True,
                                              currentUpres=self.currentUpres)
-            tk = dict(cfg=cfg, n_t_channels=self.n_t, use_batch_norm=False, train=True, currentUpres=self.currentUpres)
+            tk = dict(cfg=cfg, n_t_channels=self.n_t, use_batch_norm=self.batch_norm, train=True, currentUpres=self.currentUpres)
             self.t_fake = G.placeholder([None, cfg.n_output * self.n_t], name="t_fake")
             self.t_real = G.placeholder([None, cfg.n_output * self.n_t], name="t_real")
             self.t_gp = G.placeholder([None, cfg.n_output * self.n_t], name="t_gp")

@@ -176,6 +176,9 @@ def tempo_losses_4x(p, batch_xts, batch_yts, batch_y_pos, tile_low, up_res, chan
     L = {}
     L["t_disc_loss"] = sigmoid_ce(d_t, torch.ones_like(d_t)) * weight_dld + sigmoid_ce(g_t, torch.zeros_like(g_t))
     L["t_gen_loss"] = sigmoid_ce(g_t, torch.ones_like(g_t))
+    # useTempoL2 (multipassGAN-4x.py:815-826): sum over consecutive frame pairs of mean((frame_i - frame_i+1)^2)
+    fr = fake.reshape(-1, 3, th * th)
+    L["tl_gen_loss"] = sum(torch.mean((fr[:, i] - fr[:, i + 1]) ** 2) for i in range(2))
     return L
 
 

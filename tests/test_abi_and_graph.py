@@ -103,21 +103,24 @@ def test_gan_layer_side_effects(mpg):
     assert G.get_default_graph().variables["up/weight"].shape == (4, 4, 5, 3)
     gan2.pixel_shuffle(upres=2, stage="1")                                                # GAN.py:554-560
     assert gan2.layer.shape == (None, 32, 32, 5) and gan2.layer.op == "depth_to_space"
-    assert G.get_default_graph().variables["g_cPS1/weight"].shape == (3, 3, 5, 20)
+    assert G.get_default_graph().variables["g_cPS1/weight"].shape == (1, 1, 5, 20)
     G.reset_default_graph()
 
 
 def test_fusion_plan(mpg):
     from mpgan_amd import multipass as MP
     g = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None, prec=3)
-    launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] == "conv2d_fused"]
-    assert [e["cout"] for e in launches] == [2, 8, 128, 128, 32, 8, 2, 1]
+    launches = [e for e in g.sess.plan_summary(g.sampler) if e["kind"] in ("conv2d_fused", "conv2d_small_pair")]
+    # resBlock 0 (1 -> 2 -> 8) and resBlock 3 (8 -> 2 -> 1) are one launch each: the middle tensor stays in LDS
+    assert [(e["kind"], e["cout"]) for e in launches] == [("conv2d_small_pair", 8), ("conv2d_fused", 128), ("conv2d_fused", 128),
+                                                         ("conv2d_fused", 32), ("conv2d_fused", 8), ("conv2d_small_pair", 1)]
+    assert [e["cmid"] for e in launches if e["kind"] == "conv2d_small_pair"] == [2, 2]
     # activations between fused launches travel as G8 only; the fetched tensor is fp32
-    assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True}] * 7
+    assert [e["emit"] for e in launches[:-1]] == [{"f32": False, "g8": True}] * 5
     assert launches[-1]["emit"] == {"f32": True, "g8": False}
     # F16F6: every launch of this net has 1 or 4 cout tiles, so all of it runs in that mode
     gf = MP.Generator("gen_resnet", dict(tile_low=8, up_res=4, channels=1, upsampling_mode=2), None)   # default: F16F6
-    lf = [e for e in gf.sess.plan_summary(gf.sampler) if e["kind"] == "conv2d_fused"]
+    lf = [e for e in gf.sess.plan_summary(gf.sampler) if e["kind"] in ("conv2d_fused", "conv2d_small_pair")]
     assert all(e["prec"] == 2 for e in lf) and all(e["emit"]["g8"] and not e["emit"]["f32"] for e in lf[:-1])
     # a per-launch precision map mixes modes; every mode reads the same G8 tensor
     g8x = MP.Generator("growing_gen", dict(tile_low=8, up_res=8, channels=4, first_gen=True, filter_size=3, start_fms=256,
@@ -125,10 +128,10 @@ def test_fusion_plan(mpg):
                        prec_map=[("genBlock4/g_cA_second", 3)])
     l8 = [e for e in g8x.sess.plan_summary(g8x.sampler) if e["kind"] == "conv2d_fused"]
     assert set(e["prec"] for e in l8) == {2, 3}
-    assert [len(e["segments"]) for e in launches] == [1, 2, 1, 2, 1, 2, 1, 2]
-    assert launches[0]["segments"][0]["up_log2"] == 2 and launches[1]["segments"][1]["up_log2"] == 2
+    assert [len(e["segments"]) for e in launches] == [2, 1, 2, 1, 2, 2]
+    assert launches[0]["segments"][0]["up_log2"] == 2 and launches[0]["segments"][1]["up_log2"] == 2
     assert all(e["act"] == "relu" for e in launches)
-    other = [e["kind"] for e in g.sess.plan_summary(g.sampler) if e["kind"] != "conv2d_fused"]
+    other = [e["kind"] for e in g.sess.plan_summary(g.sampler) if e["kind"] not in ("conv2d_fused", "conv2d_small_pair")]
     assert set(other) <= {"reshape"}
     g2 = MP.Generator("growing_gen", dict(tile_low=8, up_res=8, channels=4, first_gen=False, filter_size=5,
                                           start_fms=192, max_fms=192), None)
@@ -210,5 +213,17 @@ def test_no_packed_fp32_valu(mpg):
             asm.append(subprocess.run([objdump, "-d", "--mcpu=gfx950", co], capture_output=True, text=True, check=True).stdout)
     asm = "\n".join(asm)
     assert "v_mfma_f32_32x32x16_f16" in asm                     # it is the library's device code
+    assert "v_mfma_scale_f32_32x32x64_f8f6f4" in asm and "v_cvt_scalef32_pk32_bf6_f16" in asm    # the F16F6 correction path
     packed = re.findall(r"v_pk_(?:fma|mul|add)_f32", asm)
     assert not packed, "%d packed-fp32 VALU instructions in libmpgan_hip.so" % len(packed)
+    # the matrix-core convolution kernels neither spill nor use scratch: a scratch_ instruction inside one of them means
+    # the register budget of a K loop was exceeded (round 2 shipped conv_mfma_f8_kernel<2> with 8 spilled registers)
+    body, spills = None, {}
+    for line in asm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            body = m.group(1)
+        elif body and "conv_mfma" in body and "scratch_" in line:
+            spills[body] = spills.get(body, 0) + 1
+    assert not spills, "scratch traffic in the convolution kernels: %s" % spills
+    assert len(set(re.findall(r"<(\S*conv_mfma_f6_kernel\S*)>:", asm))) == 4

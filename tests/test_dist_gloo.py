@@ -46,7 +46,7 @@ class OracleGen(object):
         return torch.as_tensor(out[..., 0])
 
 
-def _pipelines(comm):
+def _pipelines(comm, exchange="all_gather"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import mpgan_amd  # noqa: F401
@@ -58,12 +58,14 @@ def _pipelines(comm):
         low = torch.as_tensor(synthetic_volume(4, nch, 3))
         g1 = OracleGen("gen_resnet", 5, dict(up_res=4, mode=2))
         g2 = OracleGen("gen_resnet", 6, dict(up_res=4, mode=1))
-        final, v1 = MP.two_pass_4x(g1, g2, low, 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5)
+        final, v1 = MP.two_pass_4x(g1, g2, low, 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5, exchange=exchange)
         outs["4x_c%d" % nch] = final.numpy()
-        outs["4x_c%d_v1" % nch] = v1.numpy()
+        if v1 is not None:          # the all-to-all exchange never assembles the pass-1 volume on several ranks
+            outs["4x_c%d_v1" % nch] = v1.numpy()
         # the pipelined batch form (exchange of volume i under the passes of its neighbours) is the same arithmetic
         low_b = torch.as_tensor(synthetic_volume(4, nch, 5))
-        fb = MP.two_pass_4x_batch(g1, g2, [low, low_b, low], 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5)
+        fb = MP.two_pass_4x_batch(g1, g2, [low, low_b, low], 4, batch=3, comm=comm, backend=cpu_backend, vel_scale=0.5,
+                                  exchange=exchange)
         assert np.array_equal(fb[0].numpy(), final.numpy()) and np.array_equal(fb[2].numpy(), final.numpy())
         outs["4x_c%d_batch1" % nch] = fb[1].numpy()
     low = torch.as_tensor(synthetic_volume(2, 4, 4))
@@ -74,7 +76,8 @@ def _pipelines(comm):
     for g, c in zip(gens, cfgs):
         g.cfg = c
     for n in (1, 2, 3):
-        outs["8x_%dnets" % n] = MP.multipass_8x(gens[:n], low, 8, batches=(4, 2, 2), comm=comm, backend=cpu_backend).numpy()
+        outs["8x_%dnets" % n] = MP.multipass_8x(gens[:n], low, 8, batches=(4, 2, 2), comm=comm, backend=cpu_backend,
+                                                exchange=exchange).numpy()
     return outs
 
 
@@ -87,6 +90,13 @@ def _worker(rank, world, port, path):
     comm = mdist.Comm()
     assert (comm.rank, comm.world) == (rank, world)
     outs = _pipelines(comm)
+    # the all-to-all hand-over between the passes (1/R of the bytes) is the same arithmetic as the all-gather
+    for k, v in _pipelines(comm, "all_to_all").items():
+        assert np.array_equal(v, outs[k]), k
+    blk = torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6) + 100.0 * rank     # slab of a [4, 4, 6] volume
+    got = comm.all_to_all_blocks(blk, 2)
+    want = torch.cat([torch.arange(2 * 4 * 6, dtype=torch.float32).reshape(2, 4, 6) + 100.0 * q for q in range(world)], 0)
+    assert torch.equal(got, want[:, :, rank * 3:(rank + 1) * 3])
     assert comm.max_float(float(rank), torch.device("cpu")) == world - 1
     # data-parallel training: the flat gradient bucket of an optimiser is averaged over the ranks before
     # the Adam kernel (train.AdamTF.step); here with the kernel stubbed out, on CPU buffers

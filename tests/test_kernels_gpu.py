@@ -385,6 +385,44 @@ def test_conv_small_kernel_paths(gpu_ops, prec, tol):
     assert rel_l2(y1.cpu().numpy(), r1) < tol
 
 
+PAIR_CASES = [
+    # cin, cmid, cout, ka, kb, ks, up_log2, n, h, w            (h, w of the output)
+    (1, 2, 8, 5, 5, 1, 2, 2, 20, 44),        # resBlock 0 of pass 1: x4 nearest upsample fused, ragged tiles
+    (8, 2, 1, 5, 5, 1, 0, 1, 16, 64),        # resBlock 3
+    (4, 8, 8, 3, 5, 1, 0, 2, 19, 70),        # mixed filter sizes
+    (3, 2, 5, 7, 3, 3, 1, 1, 18, 34),        # 7x7 / 3x3, a 3x3 shortcut
+    (8, 8, 8, 5, 5, None, 0, 1, 33, 65),     # no shortcut
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv2d_small_pair(gpu_ops, case):
+    """a residual block of <= 8-channel convolutions as one launch (middle tensor in LDS) against the oracle's three
+    convolutions; zero padding of the MIDDLE tensor at the image border is the point the halo recomputation must get right"""
+    cin, cmid, cout, ka, kb, ks, up, n, h, w = case
+    rng = _rng(900 + PAIR_CASES.index(case))
+    xl = rng.standard_normal((n, h >> up, w >> up, cin)).astype(np.float32)
+    wa = rng.standard_normal((ka, ka, cin, cmid)).astype(np.float32)
+    wb = rng.standard_normal((kb, kb, cmid, cout)).astype(np.float32)
+    wsk = rng.standard_normal((ks, ks, cin, cout)).astype(np.float32) if ks else None
+    ba = rng.standard_normal(cmid).astype(np.float32)
+    bb = rng.standard_normal(cout).astype(np.float32)
+    sa, sb = float(O.wscale(wa.shape)), float(O.wscale(wb.shape))
+    x = O.resize_nearest_tf1(xl, h, w) if up else xl
+    mid = O.relu(O.bias_add(O.conv2d_same(x, wa * np.float32(sa)), ba))
+    ref = O.bias_add(O.conv2d_same(mid, wb * np.float32(sb)), bb)
+    if ks:
+        ss = float(O.wscale(wsk.shape))
+        ref = ref + O.conv2d_same(x, wsk * np.float32(ss))
+    ref = O.activation(ref, "lrelu")
+    for prec in (3, 2):
+        pk = lambda t, s: gpu_ops.pack_conv_weights(_t(t), wscale=s, prec=prec)
+        y, g = gpu_ops.conv2d_small_pair(_t(xl), 0, up, pk(wa, sa), pk(wb, sb), pk(wsk, ss) if ks else None, (h, w),
+                                         bias_a=_t(ba), act_a="relu", bias_b=_t(bb), act_b="lrelu", want_f32=True, want_g8=True)
+        assert rel_l2(y.cpu().numpy(), ref) < 1e-5
+        assert np.abs(gpu_ops.from_g8(g).cpu().numpy() - y.cpu().numpy()).max() <= np.abs(ref).max() * 2.0 ** -21
+
+
 @pytest.mark.parametrize("stride,k,cin,cout", [(1, 5, 3, 6), (2, 4, 2, 32), (2, 4, 32, 64), (1, 4, 128, 16), (2, 3, 5, 7)])
 def test_conv2d_direct(gpu_ops, stride, k, cin, cout):
     rng = _rng(17 + k + stride)

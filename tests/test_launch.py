@@ -62,3 +62,32 @@ def test_bench_parent_launches_children_without_touching_the_gpu():
     import json
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["value"] is None and line["n_gpus"] == 2 and "sharded_error" in line and "value_replicas" not in line
+
+
+@pytest.mark.timeout(600)
+def test_bench_train_parent_launches_children_without_touching_the_gpu():
+    """`python bench_train.py --gpus 2` with no WORLD_SIZE starts two fresh ranks through launch.spawn_ranks (it used to
+    exit with "launch with torch.distributed.run": VERDICT r2, missing 3); the parent path imports no torch.  Without a
+    GPU the ranks stop with "no GPU visible" and the parent reports that (rc != 0, no JSON line)."""
+    chk = ("import sys; sys.path.insert(0, %r); import bench_train; "
+           "assert 'torch' not in sys.modules, 'parent path imports torch'" % ROOT)
+    subprocess.run([sys.executable, "-c", chk], check=True, timeout=120)
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=500)
+    assert p.returncode != 0
+    assert 1 <= p.stderr.count("no GPU visible") <= 2, p.stderr[-2000:]
+    assert "{" not in p.stdout
+
+
+def test_bench_workloads_and_exchanges_parse():
+    """`bench.py --workload c4 --exchange all_to_all` (BASELINE configs[3] with the block exchange) is a known command line"""
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args(["--gpus", "8", "--workload", "c4", "--exchange", "all_to_all"])
+    assert (a.workload, a.exchange, a.gpus) == ("c4", "all_to_all", 8)
+    assert bench.parse_args([]).workload == "c2" and bench.parse_args([]).exchange == "all_gather"
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--exchange", "ring"])

@@ -416,6 +416,51 @@ def test_temporal_discriminator_losses_and_gradients():
     assert all(not torch.equal(tr.sess.params[n].detach(), before[n]) for n in tr.opt_t.names if n not in bn_bias)
 
 
+def test_temporal_l2_loss_of_the_4x_generator():
+    """lambda_t_l2 (useTempoL2, multipassGAN-4x.py:147-152,815-826): l2 distance of consecutive advected generator frames,
+    without the temporal discriminator; loss value and generator gradients against the float64 restatement"""
+    import contextlib
+    import io
+    import random
+    from mpgan_amd import tilecreator_t as tc
+    from mpgan_amd.train import Trainer4x
+    tile, C, up = 8, 4, 4
+    rng = np.random.default_rng(37)
+    with contextlib.redirect_stdout(io.StringIO()):
+        tiCr = tc.TileCreator(tileSizeLow=tile, simSizeLow=16, upres=up, dim=2, dim_t=3, densityMinimum=0.0,
+                              channelLayout_low="d,vx,vy,vz", channelLayout_high="d")
+        tiCr.addData(rng.random((4, 1, 16, 16, 12)).astype(np.float32), rng.random((4, 1, 64, 64, 3)).astype(np.float32))
+    random.seed(2)
+    xts, yts, ypos = tiCr.selectRandomTempoTiles(6, True, False, n_t=3, dt=0.5)
+    tr = Trainer4x(tileSizeLow=tile, upRes=up, n_inputChannels=C, batch_norm=True, device=DEV, seed=5, use_tempo=False,
+                   lambda_t_l2=0.5)
+    assert not hasattr(tr, "opt_t") and not any(n.startswith("discriminatorTempo") for n in tr.graph.variables)
+    ps = ParamSource(seed=5)
+    params = {n: ps.get(n, s.shape, s.kind) for n, s in tr.graph.variables.items()}
+    with torch.no_grad():
+        for n, t in tr.sess.params.items():
+            t.copy_(dev(params[n]))
+    full = Trainer4x(tileSizeLow=tile, upRes=up, n_inputChannels=C, batch_norm=True, device=DEV, seed=5, use_tempo=True)
+    pfull = {n: ps.get(n, s.shape, s.kind) for n, s in full.graph.variables.items()}
+    p = TR.to_params(pfull)
+    L = tr.tempo_losses(xts, yts, ypos)
+    assert sorted(L) == ["tl_gen_loss"]
+    Lr = TR.tempo_losses_4x(p, xts, yts, ypos, tile, up, C)
+    a, b = float(L["tl_gen_loss"].detach()), float(Lr["tl_gen_loss"].detach())
+    assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), (a, b)
+    gg = torch.autograd.grad(L["tl_gen_loss"], tr.opt_g.params, allow_unused=True)
+    rg = TR.grads(Lr["tl_gen_loss"], p, "g_")
+    for nme, g in zip(tr.opt_g.names, gg):
+        if nme in BN_BIASES:
+            continue
+        assert rel(g.cpu().numpy(), rg[nme]) < 2e-2, nme
+    xs, ys = rng.random((4, tile * tile * C)).astype(np.float32), rng.random((4, 32 * 32)).astype(np.float32)
+    Lg = tr.gen_step_tempo(xs, ys, xts, yts, ypos)
+    want = float(Lg["gen_loss"].detach()) + float(Lg["gen_l1_loss"].detach()) * tr.k + float(Lg["disc_loss_layer"].detach()) * tr.k2 \
+        + 0.5 * float(Lg["tl_gen_loss"].detach())
+    assert abs(float(Lg["gen_loss_complete"].detach()) - want) <= 1e-5 * abs(want)
+
+
 # ---------------------------------------------------------------------------------------------
 # f4: GAN.advect (GAN.py:173-418) -- semi-Lagrangian / MacCormack gather kernels
 # ---------------------------------------------------------------------------------------------

@@ -7,7 +7,7 @@ def per_launch(d, counter):
     path = sorted(glob.glob("%s/%s/*/*counter_collection.csv" % (src, d)))[-1]
     by = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or "conv_mfma_f8_kernel" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != counter or "conv_mfma_f6_kernel" not in r["Kernel_Name"]:
             continue
         by[r["Dispatch_Id"]] = by.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
     vals = sorted(by.values())
@@ -18,7 +18,7 @@ f, nf = per_launch("pmc_fetch", "FETCH_SIZE")
 w, nw = per_launch("pmc_write", "WRITE_SIZE")
 rd, wr = f * 1024 * 2, w * 1024
 out = {
-    "kernel": "conv_mfma_f8_kernel<NT=4> (MPG_PREC_F16F8): resBlock1 convB 5x5 128->128 + 1x1 8->128 shortcut, 8 slices of 256^2, G8 in / G8 out",
+    "kernel": "conv_mfma_f6_kernel<NT=4> (MPG_PREC_F16F6): resBlock1 convB 5x5 128->128 + 1x1 8->128 shortcut, 8 slices of 256^2, G8 in / G8 out",
     "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/roofline_probe.py 2 6 ; same with --pmc WRITE_SIZE (separate passes; tools/collect_profiles.sh), summarised by tools/pmc_to_json.py",
     "launches_averaged": [nf, nw],
     "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,

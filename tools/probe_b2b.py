@@ -14,7 +14,7 @@ a = torch.randn((n, h, h, 32), device=dev, generator=g).relu_()
 x = torch.randn((n, h, h, 128), device=dev, generator=g).relu_()
 wb = torch.randn((5, 5, 32, 8), device=dev, generator=g) * 0.03
 ws = torch.randn((1, 1, 128, 8), device=dev, generator=g) * 0.08
-ga, gx = ops.to_g8(a, flavour=ops.G8_F8C), ops.to_g8(x, flavour=ops.G8_F8C)
+ga, gx = ops.to_g8(a), ops.to_g8(x)
 pb, ps = ops.pack_conv_weights(wb, prec=2), ops.pack_conv_weights(ws, prec=2)
 
 
@@ -31,7 +31,7 @@ def timeit(fn, it=20):
     return e0.elapsed_time(e1) / it * 1e3
 
 
-print("5x5 32->8 alone      %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb)], (h, h), act="relu", want_f32=False, want_g8c=True)))
-print("1x1 128->8 alone     %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8c=True)))
-print("fused                %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb), ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8c=True)))
-print("fused, skip K loop   %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb), ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8c=True, reserved=1)))
+print("5x5 32->8 alone      %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb)], (h, h), act="relu", want_f32=False, want_g8=True)))
+print("1x1 128->8 alone     %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8=True)))
+print("fused                %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb), ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8=True)))
+print("fused, skip K loop   %.1f us" % timeit(lambda: ops.conv2d_fused([ops.Segment(ga, pb), ops.Segment(gx, ps)], (h, h), act="relu", want_f32=False, want_g8=True, reserved=1)))

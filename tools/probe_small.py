@@ -16,7 +16,7 @@ def run(cin, cout, k, extra, prec=2, iters=50):
         x2 = torch.randn((N, H, H, extra), device=dev, generator=g).relu_()
         w2 = torch.randn((1, 1, extra, cout), device=dev, generator=g)
         segs.append(ops.Segment(x2, ops.pack_conv_weights(w2, wscale=0.05, prec=prec)))
-    f = lambda: ops.conv2d_fused(segs, (H, H), act="relu", want_f32=False, want_g8c=True)
+    f = lambda: ops.conv2d_fused(segs, (H, H), act="relu", want_f32=False, want_g8=True)
     for _ in range(3): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()

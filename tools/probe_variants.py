@@ -1,4 +1,4 @@
-"""development probe: times the F16F8 matrix layers (single launches, 8 slices of 256^2) with each library under
+"""development probe: times the F16F6 matrix layers (single launches, 8 slices of 256^2) with each library under
 tools/variants/ (tools/build_variants.sh), one child process per library, round-robin twice so drift shows."""
 import os
 import subprocess

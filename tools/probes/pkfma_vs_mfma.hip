@@ -4,7 +4,7 @@
 //             fused multiply-adds: bit-identical by definition), and counts lanes whose two results differ.  No LDS, no
 //             memory traffic in the loop: only the packed-fp32 datapath is exercised.  64 VGPRs: up to four victim waves
 //             fit on a SIMD beside one 256-register matrix wave.
-//   corunner: 256 threads, 256 VGPRs (one wave per SIMD and block, like conv_mfma_f8_kernel<1>), 75 KB of LDS, a dense
+//   corunner: 256 threads, 256 VGPRs (one wave per SIMD and block, like conv_mfma_f8_kernel<1>), 100 KB of LDS (one block, i.e. one matrix wave per SIMD, per CU), a dense
 //             loop of v_mfma_f32_32x32x16_f16 + v_mfma_scale_f32_32x32x64_f8f6f4 (fp8) with LDS-DMA pieces in between.
 // Three streams as in the finding: one of co-runners, two of victims, back to back for ~2 s per mode.
 // build: hipcc --offload-arch=gfx950 -O3 -o pkfma_vs_mfma pkfma_vs_mfma.hip
@@ -42,6 +42,42 @@ __global__ __launch_bounds__(256) void victim(unsigned* bad, int iters, int use_
     }
 }
 
+// victim 2: the instruction pattern of the failing build of conv_small_kernel<1,8> (hipcc -O3 with the SLP vectoriser):
+// the 64-bit source of every v_pk_fma_f32 is assembled by two v_mov_b32 and REWRITTEN by the next two v_mov_b32 right
+// behind the packed FMA that read it (write after read, back to back):
+//     v_mov_b32 v134, a0 ; v_mov_b32 v135, b0 ; v_pk_fma_f32 acc, v[134:135], w, acc ; v_mov_b32 v134, a1 ; ...
+// The same sums are formed with scalar v_fma_f32 from the same registers; wrong lanes are recorded by quarter wave.
+__global__ __launch_bounds__(256) void victim_war(unsigned* bad, int iters) {
+    const int t = threadIdx.x + blockIdx.x * 256;
+    float a[8], b[8];
+    f2 w[4];
+    for (int i = 0; i < 8; ++i) { a[i] = 0.5f + (float)((t * 7 + i * 3) % 61) * 0.015625f; b[i] = 1.5f - (float)((t * 5 + i * 11) % 53) * 0.015625f; }
+    for (int i = 0; i < 4; ++i) { w[i].x = 0.25f + 0.03125f * i; w[i].y = -0.125f + 0.0625f * i; }
+    asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    for (int it = 0; it < iters; ++it) {
+        f2 acc = {0.f, 0.f};
+        float s0 = 0.f, s1 = 0.f;
+        // packed: acc.x += a[i] * w.x ; acc.y += b[i] * w.x  (op_sel_hi:[1,0,1]: both halves take the LOW word of w); the
+        // source pair v[62:63] is rewritten right behind every packed FMA that read it, as in the failing build
+#define STEP(i) "v_mov_b32 v62, %[a" #i "]\n\tv_mov_b32 v63, %[b" #i "]\n\tv_pk_fma_f32 %[acc], v[62:63], %[w" #i "], %[acc] op_sel_hi:[1,0,1]\n\t"
+        asm volatile(STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7)
+                     : [acc] "+v"(acc)
+                     : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [a4] "v"(a[4]), [a5] "v"(a[5]), [a6] "v"(a[6]), [a7] "v"(a[7]),
+                       [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]), [b4] "v"(b[4]), [b5] "v"(b[5]), [b6] "v"(b[6]), [b7] "v"(b[7]),
+                       [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [w4] "v"(w[0]), [w5] "v"(w[1]), [w6] "v"(w[2]), [w7] "v"(w[3])
+                     : "v62", "v63");
+#undef STEP
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(a[i]), "v"(w[i & 3].x));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(b[i]), "v"(w[i & 3].x));
+        }
+        if (__float_as_uint(acc.x) != __float_as_uint(s0) || __float_as_uint(acc.y) != __float_as_uint(s1)) atomicAdd(&bad[1 + ((threadIdx.x & 63) >> 4)], 1u);
+        a[it & 7] += 0.0078125f; b[(it + 3) & 7] -= 0.00390625f;
+        if ((it & 255) == 255) for (int i = 0; i < 8; ++i) { a[i] = 0.5f + (float)((t * 7 + i * 3 + it) % 61) * 0.015625f; b[i] = 1.5f - (float)((t * 5 + i * 11 + it) % 53) * 0.015625f; }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void corunner(const char* src, float* sink, int iters, int mode) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     f32x16 acc[12];                                   // 192 accumulator registers + operands: 256 VGPRs, one wave per SIMD
@@ -68,8 +104,8 @@ __global__ __launch_bounds__(256, 2) void corunner(const char* src, float* sink,
 
 int main() {
     unsigned* bad; char* src; float* sink;
-    CK(hipMalloc(&bad, 4)); CK(hipMalloc(&src, 64 * 4096 + 4096)); CK(hipMalloc(&sink, 4)); CK(hipMemset(src, 0x3c, 64 * 4096 + 4096));
-    CK(hipFuncSetAttribute((const void*)corunner, hipFuncAttributeMaxDynamicSharedMemorySize, 75 * 1024));
+    CK(hipMalloc(&bad, 32)); CK(hipMalloc(&src, 64 * 4096 + 4096)); CK(hipMalloc(&sink, 4)); CK(hipMemset(src, 0x3c, 64 * 4096 + 4096));
+    CK(hipFuncSetAttribute((const void*)corunner, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     hipStream_t st[3];
     for (int i = 0; i < 3; ++i) CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
     const char* names[4] = {"victims alone", "beside f16 MFMA waves", "beside f16 + fp8-scaled MFMA waves", "beside f16 + fp8 MFMA waves with LDS-DMA"};
@@ -77,7 +113,7 @@ int main() {
         for (int mode = -1; mode < 3; ++mode) {
             CK(hipMemset(bad, 0, 4));
             for (int rep = 0; rep < 40; ++rep) {
-                if (mode >= 0) hipLaunchKernelGGL(corunner, dim3(512), dim3(256), 75 * 1024, st[0], src, sink, 6000, mode);
+                if (mode >= 0) hipLaunchKernelGGL(corunner, dim3(512), dim3(256), 100 * 1024, st[0], src, sink, 6000, mode);
                 for (int v = 1; v < 3; ++v)
                     for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(victim, dim3(1024), dim3(256), 0, st[v], bad, 20000, lds);
             }
@@ -86,5 +122,18 @@ int main() {
             printf("victim %s, %-42s: %u mismatching (packed vs scalar) checks of %.3g\n", lds ? "with LDS reads" : "registers only ", names[mode + 1], h,
                    40.0 * 8 * 1024 * 256 * 6 * (20000 / 64));
         }
+    // the write-after-read pattern of the failing build
+    for (int mode = -1; mode < 3; ++mode) {
+        CK(hipMemset(bad, 0, 32));
+        for (int rep = 0; rep < 40; ++rep) {
+            if (mode >= 0) hipLaunchKernelGGL(corunner, dim3(512), dim3(256), 100 * 1024, st[0], src, sink, 6000, mode);
+            for (int v = 1; v < 3; ++v)
+                for (int q = 0; q < 4; ++q) hipLaunchKernelGGL(victim_war, dim3(1024), dim3(256), 0, st[v], bad, 20000);
+        }
+        CK(hipDeviceSynchronize());
+        unsigned h[8]; CK(hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost));
+        printf("victim v_mov / v_pk_fma_f32 / v_mov (source rewritten behind the packed FMA), %-42s: wrong sums by quarter wave [lanes 0-15, 16-31, 32-47, 48-63] = %u %u %u %u of %.3g checks\n",
+               names[mode + 1], h[1], h[2], h[3], h[4], 40.0 * 8 * 1024 * 256 * 20000);
+    }
     return 0;
 }

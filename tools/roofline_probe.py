@@ -26,6 +26,6 @@ pkb = ops.pack_conv_weights(wb, wscale=float(np.sqrt(2.0 / 3200)), prec=prec)
 pks = ops.pack_conv_weights(ws, wscale=float(np.sqrt(2.0 / 8)), prec=prec)
 segs = [ops.Segment(a, pkb), ops.Segment(x, pks)]
 for _ in range(iters):
-    ops.conv2d_fused(segs, (h, w), bias=bias, act="relu", want_f32=False, want_g8=(prec != 2), want_g8c=(prec == 2))
+    ops.conv2d_fused(segs, (h, w), bias=bias, act="relu", want_f32=False, want_g8=True)
 torch.cuda.synchronize()
 print("done")
