@@ -51,7 +51,8 @@ for name, default in [
         ("saveMetaData", 0), ("use_spatialdisc", True), ("clamping", True), ("simLowLength", 64), ("simLowWidth", 64),
         ("simLowHeight", 64), ("overlappedpixel", 3), ("startIndex", 0), ("useAvgDepool", False), ("avgMode", 0),
         ("velScale", 1.0), ("upsamplingMode", 2), ("upsampledData", False), ("sliceMode", 0), ("interpMode", 1),
-        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0), ("prec", "2")]:
+        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0), ("prec", "2"),
+        ("deviceTiles", 1)]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
 
@@ -96,13 +97,24 @@ def train_main():
         mfl = mfl + ["velocity"]
     dirIDs = np.linspace(fromSim, toSim, (toSim - fromSim + 1), dtype='int16')
     data_fraction = float(P["data_fraction"])
+    # deviceTiles 1 (default): the frames live in HBM and the batches are cut / augmented by HIP kernels
+    # (tiles_device.DeviceTileCreator: the reference's random decisions in its draw order, tilecreator_t.py:457-546,
+    # 1345-1414) and reach the trainer as device tensors; 0: the host TileCreator (numpy / scipy, one thread)
+    device_tiles = int(P["deviceTiles"]) > 0
+    if device_tiles:
+        from mpgan_amd.tiles_device import DeviceTileCreator
+
+        def Tiles(**kw):
+            return DeviceTileCreator(device=device, **kw)
+    else:
+        Tiles = tc.TileCreator
     if mode == 1:
         # second network (:234,241-248,253-262,291-299): slices along x of volumes zoomed to the high resolution,
         # their density channel replaced by the first network's output (density_low_2x2_%04d.uni)
         n_t = 3
         mol = [o for o in range(3) for _ in mfl]
         moh = [o for o in range(3) for _ in mfh]
-        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow * upRes, densityMinimum=0.005, channelLayout_high='d',
+        tiCr = Tiles(tileSizeLow=tileSizeLow * upRes, densityMinimum=0.005, channelLayout_high='d',
                               simSizeLow=simSizeLow * upRes, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=1,
                               premadeTiles=False)
         common = dict(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
@@ -114,7 +126,7 @@ def train_main():
                                   multi_file_idxOff=[0, 1, 2], **common)
         fl = FDL.FluidDataLoader(filename_y="density_high_%04d.uni", multi_file_list=mfl * 3, multi_file_idxOff=mol, **common)
     elif not useTempoD:
-        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, simSizeLow=simSizeLow, dim=2, dim_t=1, channelLayout_low=channelLayout_low,
+        tiCr = Tiles(tileSizeLow=tileSizeLow, simSizeLow=simSizeLow, dim=2, dim_t=1, channelLayout_low=channelLayout_low,
                               upres=upRes, premadeTiles=False, channelLayout_high='d')
         fl = FDL.FluidDataLoader(print_info=1, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
                                  conv_slices=True, conv_axis=0, select_random=0.1, density_threshold=0.002,
@@ -127,7 +139,7 @@ def train_main():
         n_t = 3
         mol = [o for o in range(3) for _ in mfl]
         moh = [o for o in range(3) for _ in mfh]
-        tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.005, channelLayout_high='d', simSizeLow=simSizeLow,
+        tiCr = Tiles(tileSizeLow=tileSizeLow, densityMinimum=0.005, channelLayout_high='d', simSizeLow=simSizeLow,
                               dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=upRes, premadeTiles=False)
         fl = FDL.FluidDataLoader(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
                                  conv_slices=True, conv_axis=0, select_random=0.1, density_threshold=0.002,
@@ -176,8 +188,16 @@ def train_main():
     n_in = (tileSizeLow * tileSizeLow if mode == 2 else n_out) * n_ch
 
     def getinput():
-        bx, by = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
+        if device_tiles:
+            bx, by = tiCr.selectRandomTilesDevice(batch, augment=aug)
+        else:
+            bx, by = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
         return bx.reshape(-1, n_in), by.reshape(-1, n_out)
+
+    def gettempo():
+        if device_tiles:
+            return tiCr.selectRandomTempoTilesDevice(batch, True, aug, n_t=3, dt=0.5)
+        return tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
 
     keep_max, kept = int(P["keepMax"]), []
 
@@ -215,13 +235,13 @@ def train_main():
         tempo = None
         if useTempoD:
             for _ in range(discRuns):
-                tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
+                tempo = gettempo()
                 trainer.tempo_disc_step(*tempo)
         for _ in range(genRuns):
             bx, by = getinput()
             trainer.k, trainer.k2 = k_f * trainer.k, k2_f * trainer.k2   # :1342-1343
             if useTempoD or useTempoL2:                                  # :1352-1363
-                tempo = tiCr.selectRandomTempoTiles(batch, True, aug, n_t=3, dt=0.5)
+                tempo = gettempo()
                 L = trainer.gen_step_tempo(bx, by, *tempo)
             else:
                 L = trainer.gen_step(bx, by)

@@ -57,7 +57,7 @@ for name, default in [
         ("genUni", False), ("upsampleFirst", True), ("usePixelShuffle", False), ("addBicubicUpsample", False),
         ("startingIter", 0), ("loadEmas", False), ("useVelInTDisc", False), ("upsampleMode", 1), ("lossScaling", False),
         ("stageIter", 25000), ("decayIter", 25000), ("maxFms", 256), ("use_wgan_gp", False), ("use_res_net", False),
-        ("use_mb_stddev", False), ("use_LSGAN", False), ("startFms", 512), ("filterSize", 3), ("outNNTestNo", 17),
+        ("use_mb_stddev", False), ("deviceTiles", 1), ("use_LSGAN", False), ("startFms", 512), ("filterSize", 3), ("outNNTestNo", 17),
         ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2), ("synthWeights", 0), ("prec", "2")]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
@@ -181,6 +181,9 @@ data_fraction, min_data_fraction = float(P["data_fraction"]), 0.08
 batch = int(P["batchSize"])
 aug = int(P["dataAugmentation"]) > 0
 device = "cuda:0"
+device_tiles = int(P["deviceTiles"]) > 0
+if device_tiles:
+    from mpgan_amd.tiles_device import DeviceTileCreator  # noqa: E402
 
 channelLayout_low, channelLayout_high, mfl, mfh = 'd', ('d,d' if later_net else 'd'), ["density"], ["density"]
 if useVelocities:
@@ -203,9 +206,11 @@ stride = 3
 
 def load_stage(currentUpres, first):
     """TileCreator + data of one growing stage (:290-345 at start-up, :1920-1960 at a stage change)"""
-    tiCr = tc.TileCreator(tileSizeLow=tileSizeLow, densityMinimum=0.002 if first else 0.01, channelLayout_high=channelLayout_high,
-                          simSizeLow=simSizeLow, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=currentUpres,
-                          premadeTiles=False)
+    tkw = dict(tileSizeLow=tileSizeLow, densityMinimum=0.002 if first else 0.01, channelLayout_high=channelLayout_high,
+               simSizeLow=simSizeLow, dim=2, dim_t=3, channelLayout_low=channelLayout_low, upres=currentUpres, premadeTiles=False)
+    # deviceTiles 1 (default): frames resident in HBM, batches cut / augmented by HIP kernels with the reference's random
+    # decisions (tiles_device.DeviceTileCreator; tilecreator_t.py:457-546,1345-1414); 0: the host TileCreator
+    tiCr = DeviceTileCreator(device=device, **tkw) if device_tiles else tc.TileCreator(**tkw)
     high = "density_high_%04d.uni" if currentUpres == upRes else "density_low_%i" % currentUpres + "_%04d.uni"
     off = 0 if first else stride * (int(round(math.log(currentUpres, 2))) - 1)
     common = dict(print_info=0, base_path=packedSimPath, base_path_y=packedSimPath, numpy_seed=randSeed,
@@ -277,20 +282,26 @@ if int(P["load_model_test"]) >= 0:
 
 def getinput():
     """:1497-1537 incl. the 1-in-20 empty-density batches"""
-    batch_xs, batch_ys = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
+    if device_tiles:
+        batch_xs, batch_ys = tiCr.selectRandomTilesDevice(batch, augment=aug)
+    else:
+        batch_xs, batch_ys = tiCr.selectRandomTiles(selectionSize=batch, augment=aug)
     if not min(np.random.randint(0, 20), 1):
         batch_xs[:, :, :, :, 0:1] = 0
         if add_adj_idcs:
             batch_xs[:, :, :, :, 4:6] = 0
         batch_xs[:, :, :, :, 1:4] *= (1.0 + np.random.rand() * 1.5)
         batch_ys[:, :, :, :, :] = 0
-    return np.reshape(batch_xs, (-1, cfg.n_input)), np.reshape(batch_ys, (batch, -1))
+    return batch_xs.reshape(-1, cfg.n_input), batch_ys.reshape(batch, -1)
 
 
 def getTempoinput():
-    bx, by, bp = tiCr.selectRandomTempoTiles(batch, True, aug, 3, 0.5)
+    if device_tiles:
+        bx, by, bp = tiCr.selectRandomTempoTilesDevice(batch, True, aug, 3, 0.5)
+    else:
+        bx, by, bp = tiCr.selectRandomTempoTiles(batch, True, aug, 3, 0.5)
     n = bx.shape[0]
-    return np.reshape(bx, [n, -1]), np.reshape(by, [n, -1]), np.reshape(bp, [n, -1])
+    return bx.reshape(n, -1), by.reshape(n, -1), bp.reshape(n, -1)
 
 
 save_no = 0

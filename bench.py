@@ -52,6 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--slice-batch", type=int, default=8, help="slices per generator launch (reference: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (and the oracle parity it carries)")
     ap.add_argument("--no-second-prec", action="store_true", help="skip the second timed figure (value_f16x3)")
+    ap.add_argument("--no-train-block", action="store_true", help="skip the `train_c3` block (BASELINE configs[2], ~5 s)")
     ap.add_argument("--cpu-slices", type=int, default=12, help="slices per pass of the CPU leg (>= 8)")
     ap.add_argument("--lanes", type=int, default=2,
                     help="HIP streams the independent volumes are dealt to (multipass.two_pass_4x_batch lanes)")
@@ -209,6 +210,39 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 bf6 (MX e3m2, K=64 in the cycles of one fp16 K=16): 1.5 fp16-equivalent units", 1: "1 fp16"}[prec],
     }
+
+
+def train_c3_block(device, steps=20, warmup=3):
+    """BASELINE configs[2] ("C3") next to the headline, outside its timed region: one 4x training iteration (G + D
+    forward / backward + both Adam updates; 16 tiles of 16 -> 64^2, density + velocity, batch norm, spatial discriminator,
+    replayed from the captured hipGraph) and the matrix-core weight gradient of its widest layer.  Same code as
+    `python bench_train.py`, which also has the CPU port beside it and the 256^2 / 8x variants."""
+    import numpy as np
+    import torch
+    import bench_train as BT
+    from mpgan_amd.train import Trainer4x
+    BT.torch = torch
+    tile, batch, ch = 16, 16, 4
+    rng = np.random.default_rng(0)
+    tr = Trainer4x(tileSizeLow=tile, upRes=4, n_inputChannels=ch, batch_norm=True, device=str(device))
+    xs = torch.as_tensor(rng.random((batch, tile * tile * ch)).astype(np.float32), device=device)
+    ys = torch.as_tensor(rng.random((batch, (tile * 4) ** 2)).astype(np.float32), device=device)
+    for _ in range(warmup):
+        tr.train_step_graphed(xs, ys)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d, g = tr.train_step_graphed(xs, ys)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    gf, df = BT.fwd_flops_per_tile(tile * 4, ch)
+    flops = batch * ((gf + 2 * df + 2 * 2 * df) + (gf + 2 * df + df + 2 * gf))
+    roof = BT.wgrad_roofline(device, tile * 4, batch)
+    return {"workload": "BASELINE configs[2]: 4x training step, tileSize 16 -> 64^2, batch 16, density+velocity, batchNorm, "
+                        "spatial discriminator, hipGraph replay", "iterations_per_s": round(1.0 / dt, 2),
+            "ms_per_iteration": round(dt * 1e3, 3), "steps": steps, "tiles_per_s": round(batch / dt, 1),
+            "algorithmic_tflops": round(flops / dt / 1e12, 1), "dtype": "f16x3->f32",
+            "disc_loss": float(d), "gen_loss_complete": float(g), "wgrad_roofline": roof}
 
 
 def _rel_l2(a, b):
@@ -513,6 +547,11 @@ def main(argv=None):
         worst = max(max(v.values()) for v in parity.values())
         ok = worst <= PARITY_TOL
         result["parity_ok"] = bool(ok)
+    if world == 1 and not args.no_train_block:
+        try:
+            result["train_c3"] = train_c3_block(device)
+        except Exception as e:               # noqa: BLE001 -- the headline line must not die with the side block
+            result["train_c3"] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:200] if str(e) else "")}
     print(json.dumps(result))
     sys.stdout.flush()
     return 0 if ok else 1

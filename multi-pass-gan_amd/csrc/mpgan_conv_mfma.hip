@@ -41,13 +41,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_WD
 #define MPG_WD 1
 #endif
-//   MPG_W4 1        four cout tiles: 4 waves x (4 tile rows x 4 cout tiles), ONE wave per SIMD with 256 accumulator
-//                   registers (no arbitration between two waves of a SIMD, a third fewer A-fragment reads) instead of 8 x (2 x 4)
-#ifndef MPG_W4
-#define MPG_W4 0
-#endif
+// (measured and dropped in round 3, like in round 2: four cout tiles as 4 waves x (4 tile rows x 4 cout tiles), one wave per
+// SIMD with the 256 accumulators in AccVGPRs: hipcc allocates 142 VGPRs + 256 AGPRs but keeps 1088 bytes of scratch per lane
+// in the K loop -- 15.8 ms against 0.64 ms; that shape needs hand-allocated registers: profiles/r03/kloop_variants.md)
 #ifndef MPG_DIAG6
 #define MPG_DIAG6 0
+#endif
+//   MPG_ALT 1       experiment, off: the second half of the waves of an 8-wave block runs a stage's correction steps BEFORE its
+//                   fp16 groups (complementary phases on a SIMD).  As compiled the corrections-first order keeps 265 spilled
+//                   registers at four cout tiles (profiles/r03/kloop_variants.md): not measured on the hardware
+#ifndef MPG_ALT
+#define MPG_ALT 0
+#endif
+//   MPG_MIX 1       8-wave kernels: the NT steps `w_lo6 x a_hi6` ride in the last NT fp16 groups of the stage (their operands
+//                   prefetched like the fp16 ones) instead of forming half of a separate, latency-bound correction phase
+#ifndef MPG_MIX
+#define MPG_MIX 0
 #endif
 //   MPG_STAMPS 1    diagnostic build only: every wave accumulates, over the stages of its K loop, the s_memtime cycles from
 //                   the barrier release to (0) its first MFMA wait satisfied, (1) the end of the fp16 groups, (2) the end
@@ -177,6 +186,44 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[PT][NT], const KArgs
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[pt][nt][i] *= sc;
+        }
+        if (a.y == nullptr && a.post_add == nullptr) {
+            // G8 output only (every launch between two fused convolutions): no LDS staging.  An accumulator quad holds
+            // channels 8 q + 4 hh .. + 3 of pixel r, i.e. the two lanes (r, hh = 0 / 1) share every 8-channel group.
+            // v_permlane32_swap trades the upper half-wave of one quad register with the lower half-wave of another:
+            // after four swaps lane (r, 0) holds all 8 channels of group gA and lane (r, 1) all 8 of group gB, ready
+            // to be split into the hi / lo planes and stored as 512-byte runs per plane and half-wave.
+            const int npx = min(32, a.w - x0);
+            if (py < a.h && r < npx && !(a.dbg & 2)) {
+                const size_t plane_px = (size_t)a.h * a.w;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+                            const v2u_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[pt][nt][8 * qp + i]),
+                                                                              __float_as_uint(acc[pt][nt][8 * qp + 4 + i]), false, false);
+                            v[i] = __uint_as_float(sw[0]);
+                            v[4 + i] = __uint_as_float(sw[1]);
+                        }
+                        const int cg = nt * 4 + 2 * qp + hh;
+                        if (cg < cg_out) {
+                            char* dst = a.y_g8 + ((((size_t)n * cg_out + cg) * 2) * plane_px + (size_t)py * a.w + x0 + r) * 16;
+                            half8 hi, lo;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                hi[j] = (_Float16)v[j];
+                                lo[j] = (_Float16)(v[j] - (float)hi[j]);
+                            }
+                            __builtin_nontemporal_store(hi, reinterpret_cast<half8*>(dst));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<half8*>(dst + plane_px * 16));
+                        }
+                    }
+            }
+            continue;
         }
         // stage this wave's 32 pixels x cout through LDS ([pixel][cout] rows padded by 16 B); the 32
         // pixels of a tile row are contiguous in every output layout, so all stores are whole runs
@@ -516,7 +563,7 @@ constexpr int BF6 = 3;     // cbsz / blgp code of e3m2
 
 template <int NT>
 struct Pipe6 {
-    static constexpr int WAVES = (NT == 1 || (NT == 4 && MPG_W4)) ? 4 : 8;
+    static constexpr int WAVES = (NT == 1) ? 4 : 8;
     static constexpr int PT = 16 / WAVES;                  // tile rows per wave
     static constexpr int TH = 16;
     static constexpr int WF16 = 4 * NT * 1024;             // four fp16 k-steps
@@ -529,7 +576,7 @@ struct Pipe6 {
 };
 
 template <int NT>
-__global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, (NT == 4 && MPG_W4) ? 1 : 2) void conv_mfma_f6_kernel(const ConvArgs a_unused) {
+__global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(const ConvArgs a_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     const auto& a = *ap;
@@ -736,6 +783,8 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, (NT == 4 && MPG_W4) ? 1 : 2)
         unsigned sum_head = 0, sum_f16 = 0, sum_f6 = 0, sum_bar = 0;
 #endif
 
+        auto run_stages = [&](auto oc) {
+        constexpr bool CORR_FIRST = decltype(oc)::value != 0;
         for (int st = 0; st < NS; ++st) {
             // stage st (and everything older, incl. the images issued before it) has landed; all waves are done
             // with stage st-1
@@ -803,46 +852,156 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, (NT == 4 && MPG_W4) ? 1 : 2)
                 sb[pt] = (e16[pt] + 109) | (e16[pt] + 97) << 8;
 #endif
             };
-            static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
             constexpr int HALF = G16 / 2;
             constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
             constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
-            // ---- the fp16 product: G16 groups of PT MFMAs ----
-            static_for<0, G16>([&](auto gc) {
-                constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                if constexpr (g < HALF) {
-                    if (do_img)
-                        static_for<0, IPG>([&](auto kc) {
-                            constexpr int i = g * IPG + decltype(kc)::value;
-                            if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
-                        });
-                } else {
-                    static_for<0, WPG>([&](auto kc) {
-                        constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
-                        if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
-                    });
+#if MPG_MIX
+            // ---- mixed schedule (8-wave kernels): all B fragments of the stage at its head, the a_hi codes made behind the
+            // first groups, and the NT steps w_lo6[k] x a_hi6 inside the last NT fp16 groups; only the NT steps
+            // w_hi6 x a_lo6 remain behind the fp16 groups.  Reads issued by group h: A(h + 2) and, when h + 2 is the group of
+            // correction step k, the two halves of w_lo6[k] right behind it.
+            v4i wm[3][2];
+            constexpr int GK0 = G16 - NT;                              // group of correction step 0
+            auto mix_reads = [&](auto hc) {                           // the reads group h issues (h = -2, -1: the stage head)
+                constexpr int t = decltype(hc)::value;                // target group t = h + 2
+                if constexpr (t < G16) {
+                    ds_read16<t * 1024>(aq[t % (AH + 1)], a_base);
+                    if constexpr (t >= GK0) {
+                        constexpr int k = t - GK0, off = WF16 + WF6 + k * 2048;
+                        ds_read16<off>(wm[k % 3][0], a_base);
+                        ds_read16<off + 1024>(wm[k % 3][1], a_base);
+                    }
                 }
-                if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
-                lgkm_wait<kx_allowed(g, NT, PT, AH)>();        // reads issued behind group g's own
-                if constexpr (g == 0) { MPG_STAMP(ts1); }
-                tie(aq[g % (AH + 1)]);
-                if constexpr (nt == 0)
-                    static_for<0, PT>([&](auto pc) { tie(bh[decltype(pc)::value][j]); });
+            };
+            auto fp16_mix = [&]() {
                 static_for<0, PT>([&](auto pc) {
                     constexpr int pt = decltype(pc)::value;
-                    acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(pixb[pt] + to16[j]));
+                    });
                 });
-                // the a_hi block scales and codes (VALU work under the matrix pipe): tile row g - 3 NT behind each group of
-                // the last k-step, whatever is left behind the last group
-                if constexpr (g >= 3 * NT && g - 3 * NT < PT) make_hi6(std::integral_constant<int, g - 3 * NT>{});
-                if constexpr (g == G16 - 1 && NT < PT) static_for<NT, PT>([&](auto pc) { make_hi6(pc); });
-            });
-            MPG_STAMP(ts2);
+                mix_reads(std::integral_constant<int, 0>{});
+                mix_reads(std::integral_constant<int, 1>{});
+                static_for<0, G16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
+                    if constexpr (g < HALF) {
+                        if (do_img)
+                            static_for<0, IPG>([&](auto kc) {
+                                constexpr int i = g * IPG + decltype(kc)::value;
+                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
+                            });
+                    } else {
+                        static_for<0, WPG>([&](auto kc) {
+                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
+                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
+                        });
+                    }
+                    mix_reads(std::integral_constant<int, g + 2>{});
+                    // reads issued behind group g's own: those of groups g - 1 and g
+                    constexpr int n1 = (g + 1 < G16 ? 1 + (g + 1 >= GK0 ? 2 : 0) : 0), n2 = (g + 2 < G16 ? 1 + (g + 2 >= GK0 ? 2 : 0) : 0);
+                    lgkm_wait<n1 + n2>();
+                    if constexpr (g == 0) { MPG_STAMP(ts1); }
+                    tie(aq[g % (AH + 1)]);
+                    if constexpr (g == 0)
+                        static_for<0, PT>([&](auto pc) {
+                            static_for<0, 4>([&](auto jc) { tie(bh[decltype(pc)::value][decltype(jc)::value]); });
+                        });
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
+                    });
+                    if constexpr (g < PT) make_hi6(std::integral_constant<int, g>{});
+                    if constexpr (g >= GK0) {
+                        constexpr int k = g - GK0;
+                        tie(wm[k % 3][0]);
+                        tie(wm[k % 3][1]);
+                        const v8i w6 = __builtin_shufflevector(wm[k % 3][0], wm[k % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        static_for<0, PT>([&](auto pc) {
+                            constexpr int pt = decltype(pc)::value;
+                            acc[pt][k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, hi6[pt], acc[pt][k], BF6, BF6, 1, w6[6], 0, sb[pt]);
+                        });
+                    }
+                });
+            };
+            auto lo_mix = [&]() {      // the NT steps w_hi6[k] x a_lo6: a_lo fragments into the a_hi registers, w_hi6 one step ahead
+                v4i wq[2][2];
+                auto read_wh = [&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    ds_read16<WF16 + k * 2048>(wq[k & 1][0], a_base);
+                    ds_read16<WF16 + k * 2048 + 1024>(wq[k & 1][1], a_base);
+                };
+                read_wh(std::integral_constant<int, 0>{});
+                static_for<0, PT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(plane_b + pixb[pt] + to16[j]));
+                    });
+                });
+                if constexpr (NT > 1) read_wh(std::integral_constant<int, 1>{});
+                static_for<0, NT>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k >= 1 && k + 1 < NT) read_wh(std::integral_constant<int, k + 1>{});
+                    lgkm_wait<(k == 0 ? 4 * PT : 0) + (k + 1 < NT ? 2 : 0)>();
+                    tie(wq[k & 1][0]);
+                    tie(wq[k & 1][1]);
+                    if constexpr (k == (NT > 1 ? 1 : 0))
+                        static_for<0, PT>([&](auto pc) {
+                            constexpr int pt = decltype(pc)::value;
+                            static_for<0, 4>([&](auto jc) { tie(bh[pt][decltype(jc)::value]); });
+                            lo6[pt] = bf6_of(cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]), e16[pt] + 97);
+                        });
+                    const v8i w6 = __builtin_shufflevector(wq[k & 1][0], wq[k & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        acc[pt][k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, lo6[pt], acc[pt][k], BF6, BF6, 0, w6[6], 1, sb[pt]);
+                    });
+                });
+            };
+#endif
+            // ---- the fp16 product: G16 groups of PT MFMAs ----
+            auto fp16_phase = [&](auto mk) {
+                constexpr bool MAKE_HI6 = decltype(mk)::value != 0;
+                static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
+                static_for<0, G16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
+                    if constexpr (g < HALF) {
+                        if (do_img)
+                            static_for<0, IPG>([&](auto kc) {
+                                constexpr int i = g * IPG + decltype(kc)::value;
+                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
+                            });
+                    } else {
+                        static_for<0, WPG>([&](auto kc) {
+                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
+                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
+                        });
+                    }
+                    if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
+                    lgkm_wait<kx_allowed(g, NT, PT, AH)>();        // reads issued behind group g's own
+                    if constexpr (g == 0 && MAKE_HI6) { MPG_STAMP(ts1); }
+                    tie(aq[g % (AH + 1)]);
+                    if constexpr (nt == 0)
+                        static_for<0, PT>([&](auto pc) { tie(bh[decltype(pc)::value][j]); });
+                    static_for<0, PT>([&](auto pc) {
+                        constexpr int pt = decltype(pc)::value;
+                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
+                    });
+                    // the a_hi block scales and codes (VALU work under the matrix pipe): tile row g - 3 NT behind each group
+                    // of the last k-step, whatever is left behind the last group
+                    if constexpr (MAKE_HI6) {
+                        if constexpr (g >= 3 * NT && g - 3 * NT < PT) make_hi6(std::integral_constant<int, g - 3 * NT>{});
+                        if constexpr (g == G16 - 1 && NT < PT) static_for<NT, PT>([&](auto pc) { make_hi6(pc); });
+                    }
+                });
+            };
             // ---- the two bf6 corrections: step k < NT is w_lo6[k] x a_hi6, step k >= NT is w_hi6[k - NT] x a_lo6 ----
-            // LDS reads in order: W(0), the a_lo fragments of the first two tile rows (into the registers of their a_hi
-            // ones, which the conversions above have consumed), W(1) .. W(WD), then W(k + WD) ahead of step k.
+            // LDS reads in order: W(0), the a_lo fragments (into the registers of the a_hi ones, which the conversions
+            // above have consumed), W(1) .. W(WD), then W(k + WD) ahead of step k.
+            auto bf6_phase = [&]() {
 #if !(MPG_DIAG6 & 1)
-            constexpr int PB = PT < 2 ? PT : 2;
+            constexpr int PB = PT;                                 // all a_lo fragments at once: they land in the a_hi registers
             constexpr int KS6 = 2 * NT;                            // correction steps
             constexpr int WD = MPG_WD < KS6 - 1 ? MPG_WD : KS6 - 1;
             v4i wq[WD + 1][2];
@@ -900,8 +1059,53 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, (NT == 4 && MPG_W4) ? 1 : 2)
 #else
             asm volatile("" ::"v"(hi6[0]), "v"(sb[0]), "v"(e16[0]));
 #endif
+            };
+            // The two waves of a SIMD (wave w and w + WAVES / 2 of an 8-wave block) walk the stage in OPPOSITE orders: the
+            // first half runs the matrix-dense fp16 groups first and the latency- and VALU-bound correction steps last,
+            // the second half the other way round (all operands of a stage are there at its barrier).  Run in the same
+            // order the older wave of a SIMD wins every arbitration, finishes after ~3300 cycles and idles, and the
+            // younger one ends the stage alone in its correction steps at < 50 % matrix duty (profiles/r03/kloop_stamps.txt).
+            if constexpr (CORR_FIRST) {
+                static_for<0, PT>([&](auto pc) {
+                    constexpr int pt = decltype(pc)::value;
+                    static_for<0, 4>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(pixb[pt] + to16[j]));
+                    });
+                });
+                lgkm_wait<0>();
+                static_for<0, PT>([&](auto pc) {
+                    static_for<0, 4>([&](auto jc) { tie(bh[decltype(pc)::value][decltype(jc)::value]); });
+                    make_hi6(pc);
+                });
+                MPG_STAMP(ts1);
+                bf6_phase();
+                MPG_STAMP(ts2);
+                fp16_phase(std::integral_constant<int, 0>{});
+            } else {
+#if MPG_MIX
+                if constexpr (WAVES == 8) {
+                    fp16_mix();
+                    MPG_STAMP(ts2);
+                    lo_mix();
+                } else
+#endif
+                {
+                    fp16_phase(std::integral_constant<int, 1>{});
+                    MPG_STAMP(ts2);
+                    bf6_phase();
+                }
+            }
             MPG_STAMP(ts3);
         }
+        };
+        // one loop per order, chosen once per segment (a branch inside the stage body would merge the two register
+        // allocations at every stage: 390 spilled registers when tried)
+#if MPG_ALT
+        if (WAVES == 8 && wave_u >= WAVES / 2) run_stages(std::integral_constant<int, 1>{});
+        else
+#endif
+            run_stages(std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
 #if MPG_STAMPS
@@ -1145,9 +1349,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(SmallArgs a) {
                     const float4* src = tile + (yg * SM_RPT + r) * tw + lx + kx;
                     const float4 p0 = src[0];
                     rows[r][0] = p0.x;
-                    if (CP > 1) rows[r][1] = p0.y;
-                    if (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
-                    if (PL > 1) {
+                    if constexpr (CP > 1) rows[r][1] = p0.y;
+                    if constexpr (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
+                    if constexpr (PL > 1) {
                         const float4 p1 = src[th * tw];
                         rows[r][4] = p1.x; rows[r][5] = p1.y; rows[r][6] = p1.z; rows[r][7] = p1.w;
                     }
@@ -1287,9 +1491,9 @@ __device__ __forceinline__ void small_column(const float4* tile, int tw, int pla
                 const float4* src = tile + (row0 + r) * tw + col + kx;
                 const float4 p0 = src[0];
                 rows[r][0] = p0.x;
-                if (CP > 1) rows[r][1] = p0.y;
-                if (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
-                if (PL > 1) {
+                if constexpr (CP > 1) rows[r][1] = p0.y;
+                if constexpr (CP > 2) { rows[r][2] = p0.z; rows[r][3] = p0.w; }
+                if constexpr (PL > 1) {
                     const float4 p1 = src[plane_px];
                     rows[r][4] = p1.x; rows[r][5] = p1.y; rows[r][6] = p1.z; rows[r][7] = p1.w;
                 }
@@ -1575,7 +1779,7 @@ SegShape seg_shape(int kh, int kw, int cin, int nt, int prec) {
 
 // ---- MPG_PREC_F16F6 shapes (host mirror of Pipe6<NT>) ----
 bool f6_supported(int nt) { return nt >= 1 && nt <= 4; }
-int f6_waves(int nt) { return (nt == 1 || (nt == 4 && MPG_W4)) ? 4 : 8; }
+int f6_waves(int nt) { return nt == 1 ? 4 : 8; }
 
 SegShape seg_shape_f6(int kh, int kw, int cin, int nt) {
     // nchunks = channel groups (one LDS halo image each), sc = weight stages of the whole segment

@@ -389,6 +389,58 @@ __global__ __launch_bounds__(256) void transpose_tiled_kernel(const float* __res
     }
 }
 
+// The same tile with 16-byte accesses in BOTH directions (round 3): 4-byte-per-lane loads and stores reach ~4 TB/s on
+// this chip (profiles/r02/hbm_kernels.md), 16-byte ones the copy rate.  Load: thread (row a, quad b4) reads a float4
+// along the input's innermost axis b (a wave instruction = four 256-byte rows) and stores it to LDS at [a][b4 ^ (a >> 2)].
+// Store: thread (quad ag of a, quad bq of b) reads the four float4 tile[4 ag + i][bq], transposes the 4 x 4 block in
+// registers and writes four float4 along the output's innermost axis a (again four 256-byte rows per wave instruction).
+// The XOR swizzle makes both the LDS writes (16 lanes of one row: 16 distinct quads) and the LDS reads (16 lanes with
+// ag = 0..15 and one bq: quads bq ^ ag, all distinct) conflict-free without padding.  Needs every extent and stride
+// to be a multiple of 4 elements and 16-byte aligned pointers; the scalar kernel above takes the rest.
+typedef float f4t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void transpose_tiled4_kernel(const float* __restrict__ v, TileArgs a, float* __restrict__ out) {
+    __shared__ f4t tile4[64][16];
+    int bid = blockIdx.x;
+    const int tb = bid % a.tiles_b; bid /= a.tiles_b;
+    const int ta = bid % a.tiles_a;
+    const int rr = bid / a.tiles_a;
+    const int a0 = ta * 64, b0 = tb * 64;
+    const float* src = v + (size_t)rr * a.sin_r;
+    {
+        const int b4 = threadIdx.x & 15, ar = threadIdx.x >> 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int la = ar + 16 * k;
+            const int ia = a0 + la, ib = b0 + 4 * b4;
+            f4t x = {0.f, 0.f, 0.f, 0.f};
+            if (ia < a.da && ib < a.db) x = __builtin_nontemporal_load(reinterpret_cast<const f4t*>(src + (size_t)ia * a.sin_a + ib));
+            tile4[la][b4 ^ (la >> 2)] = x;
+        }
+    }
+    __syncthreads();
+    float* dst = out + (size_t)rr * a.sout_r;
+    const int ag = threadIdx.x & 15, bq = threadIdx.x >> 4;
+    f4t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = tile4[4 * ag + i][bq ^ ag];
+    const int ia = a0 + 4 * ag;
+    if (ia < a.da) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ib = b0 + 4 * bq + j;
+            if (ib < a.db) {
+                f4t o = {r[0][j], r[1][j], r[2][j], r[3][j]};
+                if (a.cutoff > 0.f) {
+                    o.x = o.x < a.cutoff ? 0.f : o.x; o.y = o.y < a.cutoff ? 0.f : o.y;
+                    o.z = o.z < a.cutoff ? 0.f : o.z; o.w = o.w < a.cutoff ? 0.f : o.w;
+                }
+                __builtin_nontemporal_store(o, reinterpret_cast<f4t*>(dst + (size_t)ib * a.sout_b + ia));
+            }
+        }
+    }
+}
+
 __global__ void add_adjacent_kernel(const float* __restrict__ in, int s_total, size_t hw, int c, int s_off,
                                     int s_cnt, float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * BLK + threadIdx.x;
@@ -667,6 +719,13 @@ extern "C" int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0,
         t.sout_b = sout_of_in[2]; t.sout_r = sout_of_in[ax_r];
         t.tiles_a = (t.da + TRT - 1) / TRT; t.tiles_b = (t.db + TRT - 1) / TRT;
         t.cutoff = cutoff;
+        if (TRT == 64 && (t.da & 3) == 0 && (t.db & 3) == 0 && (t.sin_a & 3) == 0 && (t.sin_r & 3) == 0 && (t.sout_b & 3) == 0 &&
+            (t.sout_r & 3) == 0 && ((uintptr_t)v & 15) == 0 && ((uintptr_t)out & 15) == 0) {
+            const size_t nb4 = (size_t)t.tiles_a * t.tiles_b * t.dr;
+            MPG_REQUIRE(nb4 < (1UL << 31), "mpg_volume_transpose: grid too large");
+            hipLaunchKernelGGL(transpose_tiled4_kernel, dim3((unsigned)nb4), dim3(BLK), 0, (hipStream_t)stream, v, t, out);
+            MPG_LAUNCH_CHECK("transpose_tiled4_kernel");
+        }
         const size_t nblk = (size_t)t.tiles_a * t.tiles_b * t.dr;
         MPG_REQUIRE(nblk < (1UL << 31), "mpg_volume_transpose: grid too large");
         constexpr size_t tile_bytes = (size_t)TRT * (TRT + 1) * sizeof(float);

@@ -15,6 +15,8 @@ DEFAULT_PREC = PREC_F16X3     # kernel-level default (weight packing, generic se
 # what the inference drivers and multipass.Generator run unless told otherwise (`prec` parameter): held to
 # 5e-4 relative L2 of the oracle at the full C2 / C4 sizes by tests/test_fullsize_gpu.py (north_star: 1e-3)
 INFERENCE_PREC = PREC_F16F6
+# contractions up to this length run as MPG_PREC_F16X3 inside an F16F6 session (session._match_fused)
+F16F6_MIN_K = 256
 
 
 def parse_prec(v):

@@ -416,6 +416,12 @@ class Session(object):
         if prec == ops.PREC_F16F6 and not ops.f6_available(
                 cout, [(sg[3].conv.inputs[1].shape[0], sg[3].conv.inputs[1].shape[1], sg[5]) for sg in segs]):
             prec = ops.PREC_F16X3      # shapes the F16F6 kernels do not cover keep the fp16 split
+        # short contractions on wide outputs (8 -> 128 5x5 of resBlock 1: K = 200, four cout tiles): a launch of 4 weight
+        # stages per tile is all prologue, barriers and conversions; the three-product fp16 kernel (8-KB stages, no
+        # conversions) is faster there AND fp32-grade (109 against 124 us per 8 slices, profiles/r03/kloop_variants.md)
+        total_k = sum(sg[3].conv.inputs[1].shape[0] * sg[3].conv.inputs[1].shape[1] * sg[5] for sg in segs)
+        if prec == ops.PREC_F16F6 and total_k <= ops.F16F6_MIN_K and cout > 8:
+            prec = ops.PREC_F16X3
 
         emit = {"f32": True, "g8": False}
 

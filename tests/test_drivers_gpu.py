@@ -220,6 +220,15 @@ def test_4x_training_driver(tmp_path, lambda_t):
     assert "generator/g_cB1/weight" in p1 and p1["generator/g_cB1/weight"].shape == (5, 5, 128, 128)
     assert ("discriminatorTempo/t_c1/weight" in p1) == (lambda_t > 0)
     assert not np.array_equal(p0["generator/g_cB1/weight"], p1["generator/g_cB1/weight"])
+    # the run above cut its batches on the GPU (deviceTiles 1, the default); the host TileCreator (deviceTiles 0) draws the
+    # same tiles from the same seeds: the first iteration's discriminator loss (initial weights, first batch) is the same
+    # number.  (Trained weights are no yardstick: Adam turns gradients at the noise level into +-lr steps.)
+    import re
+    (tmp_path / "models_host").mkdir()
+    host_args = [str(tmp_path / "models_host") + "/" if a == str(tmp_path / "models") + "/" else a for a in args]
+    out_h = _run("multipassGAN-4x.py", host_args + ["deviceTiles", 0, "trainingEpochs", 1], str(tmp_path))
+    first = [float(re.search(r"disc: loss: train_loss=([0-9.eE+-]+)", o).group(1)) for o in (out, out_h)]
+    assert abs(first[0] - first[1]) <= 2e-5 * max(abs(first[1]), 1.0), first
     assert all(np.isfinite(v).all() for v in p1.values())
     # the trained generator runs in output mode
     _run("multipassGAN-4x.py", ["upRes", up, "out", 1, "tileSize", sim, "simSize", sim, "fromSim", 1005, "toSim", 1005,

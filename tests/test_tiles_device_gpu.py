@@ -41,8 +41,6 @@ def _seed(i):
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
 def test_device_tiles_match_host(name):
     sc = SCENARIOS[name]
-    if not np.isscalar(sc["upres"]):
-        pytest.skip("per-axis upres goes through the reference's hard-coded 8x branch: host path only")
     low, high = make_frames(sc)
     host, dev = _pair(sc, low, high)
     calls = {"batch": dict(n=5, tr=True, aug=False, t=1), "batch_test": dict(n=3, tr=False, aug=False, t=1),

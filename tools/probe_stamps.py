@@ -11,8 +11,6 @@ dev = "cuda:0"
 N, H = 8, 256
 for name, cin, cout, waves in (("b1.B 128->128", 128, 128, 8), ("b2.A 128->32", 128, 32, 4), ("96->96 3x3", 96, 96, 8)):
     k = 3 if "3x3" in name else 5
-    if cout == 128 and os.environ.get("MPG_STAMP_W4"):
-        waves = 4
     g = torch.Generator(device=dev).manual_seed(1)
     x = torch.randn((N, H, H, cin), device=dev, generator=g).relu_()
     w = torch.randn((k, k, cin, cout), device=dev, generator=g)
