@@ -48,32 +48,37 @@ def wgrad_roofline(device, tile_high, batch, iters=10, k=5, c=128):
     g = torch.Generator(device=device).manual_seed(1)
     x = torch.randn((batch, tile_high, tile_high, c), device=device, generator=g).relu_()
     dy = torch.randn((batch, tile_high, tile_high, c), device=device, generator=g) * 1e-4
-    # as the training step issues it (train.ConvLayerFn.backward): max |dy| comes from the kernel that produced dy, x is a
-    # forward activation and is split unscaled
+    # as the training step issues it (train.ConvLayerFn.backward): x is the G8 operand of the forward launch (kept), dy is
+    # converted to G8 once for both gradient kernels, scaled by the max |dy| that the kernel producing dy returns; the
+    # conversion is timed with the weight gradient although the data gradient shares it
     from mpgan_amd import ops
-    dy_amax, x_amax = ops.absmax(dy), train_ops.unit_amax(x.device)
+    dy_amax = ops.absmax(dy)
+    xg = ops.to_g8(x)
+
+    def call():
+        return train_ops.conv2d_wgrad_g8(xg, ops.to_g8(dy, amax=dy_amax), k, k, 0.025, 3, None, dy_amax)
     for _ in range(2):
-        train_ops.conv2d_wgrad_mfma(x, dy, k, k, 0.025, 3, dy_amax, x_amax)
+        call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
     e0.record()
     for _ in range(iters):
-        train_ops.conv2d_wgrad_mfma(x, dy, k, k, 0.025, 3, dy_amax, x_amax)
+        call()
     e1.record()
     torch.cuda.synchronize(device)
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * k * k * c * c * tile_high * tile_high * batch
     ach = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per call from the committed PMC passes (profiles/r02/roofline_pmc_wgrad.json), which were taken
+    # HBM bytes per call from the committed PMC passes (profiles/r03/roofline_pmc_wgrad.json), which were taken
     # on exactly one shape; other shapes report null
     traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02", "roofline_pmc_wgrad.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03", "roofline_pmc_wgrad.json")
     if (k, c, batch, tile_high) == (5, 128, 16, 256) and os.path.exists(pmc):
         with open(pmc) as f:
             per = json.load(f)["per_kernel_per_call"]
         traffic = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for kname, v in per.items() if "absmax" not in kname)
-    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_mfma %dx%d %d->%d (P16 rewrite + wgrad_mfma_kernel; abs-max values handed in), "
-                                       "%d tiles of %d^2" % (k, k, c, c, batch, tile_high),
+    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_g8 %dx%d %d->%d (scaled G8 conversion of dy + wgrad_mfma_kernel; x = the forward "
+                                       "launch's G8 operand), %d tiles of %d^2" % (k, k, c, c, batch, tile_high),
             "achieved": round(ach, 2), "peak": DENSE_F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / DENSE_F16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(ms, 4),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "mfma_products_per_mac": "3 fp16"}

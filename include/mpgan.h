@@ -263,9 +263,10 @@ int mpg_depth_to_space(mpg_stream_t stream, const float* x, int n, int h, int w,
 int mpg_conv2d_wgrad(mpg_stream_t stream, const float* x, int n, int h, int w, int cin, const float* dy,
                      int cout, int kh, int kw, int stride_h, int stride_w, float wscale, float* dw);
 /* The same weight gradient on the matrix cores for stride-1 filters (kh <= 7, kw in 1,3,4,5):
- * x and dy are rewritten channel-major in fp16 (hi + lo planes, power-of-two scaled) inside
+ * x and dy are converted to G8 (fp16 hi + lo planes, power-of-two scaled; mpg_f32_to_g8_scaled) inside
  * `workspace` (>= mpg_conv2d_wgrad_mfma_ws_bytes, 256-byte aligned), then contracted over pixels
- * with v_mfma_f32_32x32x16_f16.  prec MPG_PREC_F16X3 (three products, fp32-grade) or MPG_PREC_F16X1.
+ * with v_mfma_f32_32x32x16_f16, the pixel-major fragments read out of the channel-grouped G8 rows with the
+ * transposing LDS read (ds_read_b64_tr_b16).  prec MPG_PREC_F16X3 (three products, fp32-grade) or MPG_PREC_F16X1.
  * dy_amax / x_amax (device scalars, may be NULL): max |dy| / max |x| when the caller already has them (the kernel that
  * produced dy returns it; a forward activation needs no scaling: pass a scalar holding 256.0f = scale 1) -- without
  * them each costs a reduction pass over its tensor. */
@@ -274,6 +275,12 @@ int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int
                           const float* dy, int cout, int kh, int kw, float wscale, int prec,
                           void* workspace, size_t workspace_bytes, const float* dy_amax, const float* x_amax,
                           float* dw);
+/* ... with both operands already in G8 (MPG_G8_F16, 16-byte aligned): the layer's forward input as mpg_conv2d_fused
+ * read it, and the scaled dy the data-gradient convolution reads -- no conversion pass and no workspace.
+ * x_amax / dy_amax: the device scalars the tensors were scaled with by mpg_f32_to_g8_scaled, NULL for an unscaled one.
+ * This is what tf.gradients' Conv2DBackpropFilter does for the layers of GAN.py:686-691 under multipassGAN-4x.py:880-902. */
+int mpg_conv2d_wgrad_g8(mpg_stream_t stream, const void* x_g8, int n, int h, int w, int cin, const void* dy_g8, int cout,
+                        int kh, int kw, float wscale, int prec, const float* x_amax, const float* dy_amax, float* dw);
 /* dy_amax: NULL, or a device float holding max |dy| already computed with mpg_absmax */
 /* d loss / d x of the same convolution, any stride / filter size (the strided 4x4 discriminator
  * convs, multipassGAN-4x.py:607-614).  The filter is passed with its channel axes swapped,

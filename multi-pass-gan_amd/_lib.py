@@ -132,6 +132,7 @@ PROTOTYPES = {
     "mpg_conv2d_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_conv2d_wgrad_mfma_ws_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "mpg_conv2d_wgrad_mfma": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _Z, _P, _P, _P]),
+    "mpg_conv2d_wgrad_g8": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _P, _P]),
     "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_fc_forward": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _F, _P]),
     "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),

@@ -53,11 +53,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_ALT
 #define MPG_ALT 0
 #endif
-//   MPG_MIX 1       8-wave kernels: the NT steps `w_lo6 x a_hi6` ride in the last NT fp16 groups of the stage (their operands
-//                   prefetched like the fp16 ones) instead of forming half of a separate, latency-bound correction phase
-#ifndef MPG_MIX
-#define MPG_MIX 0
-#endif
+// (measured and dropped: the NT steps `w_lo6 x a_hi6` riding in the last NT fp16 groups of the stage, operands prefetched like
+// the fp16 ones, only `w_hi6 x a_lo6` left as a separate phase: b1.B 650 us against 639, profiles/r03/kloop_variants.md)
 //   MPG_STAMPS 1    diagnostic build only: every wave accumulates, over the stages of its K loop, the s_memtime cycles from
 //                   the barrier release to (0) its first MFMA wait satisfied, (1) the end of the fp16 groups, (2) the end
 //                   of the correction steps, (3) the release of the next barrier, and writes the four sums to
@@ -855,111 +852,6 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
             constexpr int HALF = G16 / 2;
             constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
             constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
-#if MPG_MIX
-            // ---- mixed schedule (8-wave kernels): all B fragments of the stage at its head, the a_hi codes made behind the
-            // first groups, and the NT steps w_lo6[k] x a_hi6 inside the last NT fp16 groups; only the NT steps
-            // w_hi6 x a_lo6 remain behind the fp16 groups.  Reads issued by group h: A(h + 2) and, when h + 2 is the group of
-            // correction step k, the two halves of w_lo6[k] right behind it.
-            v4i wm[3][2];
-            constexpr int GK0 = G16 - NT;                              // group of correction step 0
-            auto mix_reads = [&](auto hc) {                           // the reads group h issues (h = -2, -1: the stage head)
-                constexpr int t = decltype(hc)::value;                // target group t = h + 2
-                if constexpr (t < G16) {
-                    ds_read16<t * 1024>(aq[t % (AH + 1)], a_base);
-                    if constexpr (t >= GK0) {
-                        constexpr int k = t - GK0, off = WF16 + WF6 + k * 2048;
-                        ds_read16<off>(wm[k % 3][0], a_base);
-                        ds_read16<off + 1024>(wm[k % 3][1], a_base);
-                    }
-                }
-            };
-            auto fp16_mix = [&]() {
-                static_for<0, PT>([&](auto pc) {
-                    constexpr int pt = decltype(pc)::value;
-                    static_for<0, 4>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(pixb[pt] + to16[j]));
-                    });
-                });
-                mix_reads(std::integral_constant<int, 0>{});
-                mix_reads(std::integral_constant<int, 1>{});
-                static_for<0, G16>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                    if constexpr (g < HALF) {
-                        if (do_img)
-                            static_for<0, IPG>([&](auto kc) {
-                                constexpr int i = g * IPG + decltype(kc)::value;
-                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
-                            });
-                    } else {
-                        static_for<0, WPG>([&](auto kc) {
-                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
-                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
-                        });
-                    }
-                    mix_reads(std::integral_constant<int, g + 2>{});
-                    // reads issued behind group g's own: those of groups g - 1 and g
-                    constexpr int n1 = (g + 1 < G16 ? 1 + (g + 1 >= GK0 ? 2 : 0) : 0), n2 = (g + 2 < G16 ? 1 + (g + 2 >= GK0 ? 2 : 0) : 0);
-                    lgkm_wait<n1 + n2>();
-                    if constexpr (g == 0) { MPG_STAMP(ts1); }
-                    tie(aq[g % (AH + 1)]);
-                    if constexpr (g == 0)
-                        static_for<0, PT>([&](auto pc) {
-                            static_for<0, 4>([&](auto jc) { tie(bh[decltype(pc)::value][decltype(jc)::value]); });
-                        });
-                    static_for<0, PT>([&](auto pc) {
-                        constexpr int pt = decltype(pc)::value;
-                        acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
-                    });
-                    if constexpr (g < PT) make_hi6(std::integral_constant<int, g>{});
-                    if constexpr (g >= GK0) {
-                        constexpr int k = g - GK0;
-                        tie(wm[k % 3][0]);
-                        tie(wm[k % 3][1]);
-                        const v8i w6 = __builtin_shufflevector(wm[k % 3][0], wm[k % 3][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        static_for<0, PT>([&](auto pc) {
-                            constexpr int pt = decltype(pc)::value;
-                            acc[pt][k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, hi6[pt], acc[pt][k], BF6, BF6, 1, w6[6], 0, sb[pt]);
-                        });
-                    }
-                });
-            };
-            auto lo_mix = [&]() {      // the NT steps w_hi6[k] x a_lo6: a_lo fragments into the a_hi registers, w_hi6 one step ahead
-                v4i wq[2][2];
-                auto read_wh = [&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    ds_read16<WF16 + k * 2048>(wq[k & 1][0], a_base);
-                    ds_read16<WF16 + k * 2048 + 1024>(wq[k & 1][1], a_base);
-                };
-                read_wh(std::integral_constant<int, 0>{});
-                static_for<0, PT>([&](auto pc) {
-                    constexpr int pt = decltype(pc)::value;
-                    static_for<0, 4>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        ds_read16<0>(bh[pt][j], i_base + (unsigned)(plane_b + pixb[pt] + to16[j]));
-                    });
-                });
-                if constexpr (NT > 1) read_wh(std::integral_constant<int, 1>{});
-                static_for<0, NT>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    if constexpr (k >= 1 && k + 1 < NT) read_wh(std::integral_constant<int, k + 1>{});
-                    lgkm_wait<(k == 0 ? 4 * PT : 0) + (k + 1 < NT ? 2 : 0)>();
-                    tie(wq[k & 1][0]);
-                    tie(wq[k & 1][1]);
-                    if constexpr (k == (NT > 1 ? 1 : 0))
-                        static_for<0, PT>([&](auto pc) {
-                            constexpr int pt = decltype(pc)::value;
-                            static_for<0, 4>([&](auto jc) { tie(bh[pt][decltype(jc)::value]); });
-                            lo6[pt] = bf6_of(cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]), e16[pt] + 97);
-                        });
-                    const v8i w6 = __builtin_shufflevector(wq[k & 1][0], wq[k & 1][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    static_for<0, PT>([&](auto pc) {
-                        constexpr int pt = decltype(pc)::value;
-                        acc[pt][k] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, lo6[pt], acc[pt][k], BF6, BF6, 0, w6[6], 1, sb[pt]);
-                    });
-                });
-            };
-#endif
             // ---- the fp16 product: G16 groups of PT MFMAs ----
             auto fp16_phase = [&](auto mk) {
                 constexpr bool MAKE_HI6 = decltype(mk)::value != 0;
@@ -1083,18 +975,9 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 MPG_STAMP(ts2);
                 fp16_phase(std::integral_constant<int, 0>{});
             } else {
-#if MPG_MIX
-                if constexpr (WAVES == 8) {
-                    fp16_mix();
-                    MPG_STAMP(ts2);
-                    lo_mix();
-                } else
-#endif
-                {
-                    fp16_phase(std::integral_constant<int, 1>{});
-                    MPG_STAMP(ts2);
-                    bf6_phase();
-                }
+                fp16_phase(std::integral_constant<int, 1>{});
+                MPG_STAMP(ts2);
+                bf6_phase();
             }
             MPG_STAMP(ts3);
         }

@@ -3,17 +3,22 @@
 //   dW[ky][kx][ci][co] = wscale * sum_{b,oy,ox} x[b, oy+ky-pt, ox+kx-pl, ci] * dy[b, oy, ox, co]
 //
 // is, per filter tap, a GEMM whose contraction runs over PIXELS.  v_mfma_f32_32x32x16_f16 wants the
-// 8 contraction elements of a lane contiguous, so both operands are first rewritten channel-major
-// ("P16": [N][H][C][2 planes hi,lo][Wp] fp16, Wp = W rounded up to 8, scaled by a power of two taken
-// from the tensor's absolute maximum so that small gradients stay in the fp16 normal range).  Then
-//   * a block (4 waves, one per SIMD, so each wave may hold up to 512 registers) owns one filter row ky,
+// 8 contraction elements of a lane in one register quad, while the tensors of the convolution kernels (G8:
+// [N][C/8][2 planes hi,lo][H][W][8 fp16], scaled by a power of two taken from the tensor's absolute maximum where it
+// is a gradient) keep 8 CHANNELS of a pixel together.  The kernel reads G8 as it is: the pixel rows of a channel
+// group are copied to LDS unchanged and the fragments come out of ds_read_b64_tr_b16, the transposing LDS read of
+// gfx950 (a first version rewrote both operands channel-major in memory first, "P16": two more passes over x and dy
+// and 2.3 of the 3.4 GB a call moved at 128x128 channels).  So the layer's forward input and the scaled dy of the
+// data-gradient convolution are shared with this kernel, without a conversion of their own.
+//   * a block (8 waves, two per SIMD, each with at most 6 accumulator tiles; rounds 1-2 ran 4 waves with up to 16) owns one
+//     filter row ky,
 //     up to 128 input x 128 output channels, and a range of output rows; it walks the rows in chunks
 //     of 32*KS pixels, staging the x piece (with an 8-pixel halo on both sides) and the dy piece in
-//     LDS, double buffered through registers;
+//     LDS by LDS-DMA, double buffered;
 //   * a wave owns a 32-channel ci tile, COTW co tiles and all KW taps of the row: KW*COTW accumulator
-//     tiles (20 for a 5x5 128->128 layer).  Per 16-pixel k-step it reads one 24-pixel window of x per plane (3 x ds_read_b128) and
-//     derives the KW shifted A fragments in registers (v_alignbit for odd shifts), so x is read from
-//     LDS once for all taps; dy fragments are single aligned ds_read_b128;
+//     tiles (at most 6: 256 registers per wave).  Per 16-pixel k-step it reads one 24-pixel window of x per plane (6 transposed
+//     reads of 4 pixels) and derives the KW shifted A fragments in registers (v_alignbit for odd shifts), so x is read
+//     from LDS once for all taps; a dy fragment is two transposed reads;
 //   * precision 3 adds the hi*lo and lo*hi products (fp32-grade, like MPG_PREC_F16X3); precision 1
 //     keeps hi*hi only;
 //   * partial sums of the pixel ranges are combined with fp32 atomics into dW.
@@ -54,41 +59,21 @@ __global__ void amax_init_kernel(float* __restrict__ amax, const float* __restri
     if (i < 64) amax[i] = i == 0 ? (x_amax ? *x_amax : 0.f) : (i == 1 ? (dy_amax ? *dy_amax : 0.f) : 0.f);
 }
 
-// fp32 NHWC -> P16.  block: one image row, 64 pixels, 64 channels through an LDS transpose.
-__global__ __launch_bounds__(256) void to_p16_kernel(const float* __restrict__ x, int h, int w, int c, int wp,
-                                                     const float* __restrict__ amax, _Float16* __restrict__ out) {
-    __shared__ float tile[64][65];
-    const int row = blockIdx.x;            // b*h + y
-    const int x0 = blockIdx.y * 64;
-    const int c0 = blockIdx.z * 64;
-    const float scale = pow2_scale(*amax);
-    const int tid = threadIdx.x;
-    for (int e = tid; e < 64 * 64; e += 256) {
-        const int px = e / 64, ch = e % 64;
-        float v = 0.f;
-        if (x0 + px < w && c0 + ch < c) v = x[((size_t)row * w + x0 + px) * c + c0 + ch];
-        tile[px][ch] = v * scale;
-    }
-    __syncthreads();
-    for (int e = tid; e < 64 * 8; e += 256) {
-        const int u = e % 8, ch = e / 8;
-        if (c0 + ch >= c || x0 + 8 * u >= wp) continue;
-        half8 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float v = tile[8 * u + i][ch];
-            const _Float16 hh = (_Float16)v;
-            hi[i] = hh;
-            lo[i] = (_Float16)(v - (float)hh);
-        }
-        _Float16* o = out + (((size_t)row * c + c0 + ch) * 2) * wp + x0 + 8 * u;
-        *reinterpret_cast<half8*>(o) = hi;
-        *reinterpret_cast<half8*>(o + wp) = lo;
-    }
-}
-
 #ifndef MPG_WG_DIAG
 #define MPG_WG_DIAG 0
+#endif
+#define WG_MFMA(a_, b_, c_, x_, y_, z_) ((MPG_WG_EXP & 2) ? (c_) : __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, x_, y_, z_))
+#ifndef MPG_WG_EXP         // timing experiments (results are garbage): 1 no LDS waits, 2 no MFMAs, 4 no copy of the next chunk
+#define MPG_WG_EXP 0
+#endif
+// MPG_WG_SPREAD 1 (development A/B, off): one LDS-DMA instruction of the next chunk's copy in front of each product of the
+// k-steps instead of the whole copy at the head of the chunk.  Measured on the 5x5 128->128 layer, 16 tiles of 256^2
+// (profiles/r03/wgrad_variants.md): 3.62 ms against 2.98 ms.  A wave waits for the CU's address unit at every LDS-DMA
+// instruction (~35 cycles each when the unit is free, 64 instructions per chunk and CU), and spread out, the waits of the
+// two waves of a SIMD fall into the MFMA phase of both; at the head of the chunk they cost 2100 cycles once, with idle
+// matrix pipes, and the k-steps then run undisturbed (4500 cycles for 3840 of MFMA work).
+#ifndef MPG_WG_SPREAD
+#define MPG_WG_SPREAD 0
 #endif
 #if MPG_WG_DIAG
 __device__ unsigned long long g_wg_diag[8];
@@ -96,38 +81,92 @@ __device__ unsigned long long g_wg_diag[8];
 #endif
 
 struct WgArgs {
-    const _Float16* xp;      // P16 of x  [N][H][cin_total][2][wp]
-    const _Float16* dp;      // P16 of dy [N][H][cout_total][2][wp]
-    const float* amax;       // [0] x, [1] dy
+    const char* xg;          // G8 of x  [N][x_cg][2][H][W][8]
+    const char* dg;          // G8 of dy [N][d_cg][2][H][W][8]
+    const float* x_amax;     // max |x| / max |dy| the G8 tensors were scaled with (null: unscaled)
+    const float* d_amax;
     const char* zeros;       // >= 16 zero bytes: the source of padding / out-of-row units of the LDS-DMA copy
     float* dw;               // [kh][kw][cin_total][cout_total]
-    int n, h, w, wp;
+    int n, h, w;
+    int x_cg, d_cg;          // channel groups of the two tensors
     int cin_total, cout_total, ci0, co0, cin, cout;   // channel window of this launch (cin, cout <= 128)
     int windows;                                       // equal cout windows handled by this launch (>= 1)
     int kh, pt, pl;
-    int cit, cog, ks;        // waves = cit * cog * ks = 4
+    int cit, cog, ks;        // waves = cit * cog * ks = WG_WAVES
     int chunk;               // pixels per chunk = 32 * ks
-    int xrowb, drowb;        // LDS row strides in bytes
+    int xp, dp;              // pixels (16-byte units) per LDS row of a channel group, pad included
     int nsplit, rows_per_split;
     float wscale;
 };
 
-// prefetch registers for the x piece: 10 units (a 64-pixel chunk of 128 channels, hi + lo) where the
-// accumulators leave room, else 6 (32-pixel chunks)
-constexpr int x_units(int kw, int cotw) { return kw * cotw > 12 ? 6 : 10; }
-// with the pad unit that ends every LDS row (bank spread), per thread
-constexpr int x_units_dma(int kw, int cotw) { return x_units(kw, cotw) + 2; }
+constexpr int WG_WAVES = 8, WG_THREADS = WG_WAVES * 64;
+// LDS-DMA instructions per wave for the x piece of a chunk: 6 cover a 64-pixel chunk of 128 channels, hi + lo, with the
+// halo and the pad units (2 * 16 * 84 units of 16 bytes); 5 the dy piece of 128 channels (2 * 16 * 68)
+constexpr int X_UNITS_DMA = 6;
 constexpr int D_UNITS_DMA = 5;
+constexpr int LDS_ROW_PAD = 4;       // units: a row of 16 k + 4 units starts 16 banks after its neighbour (see the reads)
+
+typedef __fp16 h4raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// 4 rows (pixels) x 16 columns (channels: two G8 groups) per 16 lanes, delivered column-major: lane i of the 16 gets channel i
+// of the 4 pixels.  Every lane must be active and its address 8-byte aligned.
+// The reads and their waits are volatile asm, in program order, with the waits counted by hand: to the compiler an LDS read
+// behind an LDS-DMA instruction may alias the DMA's target, and it puts `s_waitcnt vmcnt(0)` in front of the read -- the
+// builtin form of this read made every k-step wait for the copy of the NEXT chunk to land (the copy goes to the other
+// buffer; the barrier at the end of the chunk is what orders it against its readers).
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr(u32x2& dst, unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && OFF % 8 == 0, "ds_read_b64_tr_b16 offset");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// wait until at most N of the LDS reads issued so far are outstanding (they return in order)
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+#if !(MPG_WG_EXP & 1)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory");
+#endif
+}
+// no instruction: makes every later use of `frag` depend on the preceding (volatile) wait
+template <class T>
+__device__ __forceinline__ void tie(T& frag) {
+    asm volatile("" : "+v"(frag));
+}
+
+__device__ __forceinline__ void tr_read_at(u32x2& dst, unsigned addr, int m) {      // m is a constant after unrolling
+    switch (m) {
+        case 0: lds_read_tr<0>(dst, addr); break;
+        case 1: lds_read_tr<64>(dst, addr); break;
+        case 2: lds_read_tr<128>(dst, addr); break;
+        case 3: lds_read_tr<192>(dst, addr); break;
+        case 4: lds_read_tr<256>(dst, addr); break;
+        default: lds_read_tr<320>(dst, addr); break;
+    }
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_wg(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_wg<I + 1, N>(f);
+    }
+}
 
 template <int KW, int COTW, int PREC>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
+__global__ __launch_bounds__(WG_THREADS) void wgrad_mfma_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // equal output-channel windows of one layer run as one launch: linear block id = (jj * windows + window) * 8 + xcd, so
     // the windows of one row range are dispatched together and to the same XCD, and share the x rows through its L2
     // instead of streaming them from memory once per window
     const int nwin = a.windows;
     const int co_base = a.co0 + ((blockIdx.x / 8) % nwin) * a.cout;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave number as a scalar: everything derived from it (tile ownership, loop bounds, the placement of the copy
+    // instructions) then stays on the scalar unit; taken from threadIdx it is a vector value to the compiler
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     // XCD-aware order: the kh blocks of one row range land on the same XCD (shared L2)
     const int xcd = blockIdx.x % 8, jj = blockIdx.x / (8 * nwin);
@@ -140,16 +179,21 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 
     const int nplane = PREC == 3 ? 2 : 1;
     const int xch = a.cit * 32, dch = a.cog * COTW * 32;
-    const int xbytes = xch * nplane * a.xrowb, dbytes = dch * nplane * a.drowb;
-    char* xs[2] = {lds, lds + xbytes + dbytes};
-    char* dsm[2] = {lds + xbytes, lds + 2 * xbytes + dbytes};
+    const int gx = xch / 8, gd = dch / 8;                        // channel groups of the two LDS images
+    const int xbytes = gx * nplane * a.xp * 16, dbytes = gd * nplane * a.dp * 16;
+    // the two buffers, x image then dy image each (address arithmetic, not a pointer table: indexed by the buffer number at
+    // run time such a table lives in scratch memory)
+    auto xs = [&](int buf) { return lds + buf * (xbytes + dbytes); };
+    auto dsm = [&](int buf) { return lds + buf * (xbytes + dbytes) + xbytes; };
 
-    // global -> LDS copy: LDS-DMA, 16 bytes per lane, every wave instruction fills 1 KiB of the image linearly.  The image
-    // is [plane][channel][units of 8 pixels + one pad unit] (the pad spreads the rows over the banks; it is never
-    // written or read), so unit u = (plane * channels + channel) * units_per_row + offset lands at byte 16 u.
-    const int xupr = (a.chunk + 16) / 8 + 1, dupr = a.chunk / 8 + 1;  // units per row incl. the pad unit
-    const int xunits = xch * nplane * xupr, dunits = dch * nplane * dupr;
-    constexpr int XU = x_units_dma(KW, COTW), DU = D_UNITS_DMA;        // DMA instructions per wave and chunk
+    // global -> LDS copy: LDS-DMA, 16 bytes per lane (the 8 channels of one pixel, as G8 keeps them), every wave instruction
+    // fills 1 KiB of the image linearly.  The image is [plane][channel group][pixels of the chunk + pad units] (the pad
+    // spreads the rows over the banks; it is never written or read), so unit u = (plane * groups + group) * units_per_row
+    // + pixel lands at byte 16 u.
+    const int xupr = a.xp, dupr = a.dp;                               // units per row incl. the pad units
+    const int xpx = a.chunk + 16, dpx = a.chunk;                      // ... that are pixels
+    const int xunits = gx * nplane * xupr, dunits = gd * nplane * dupr;
+    constexpr int XU = X_UNITS_DMA, DU = D_UNITS_DMA;                  // DMA instructions per wave and chunk
     const int total_rows = a.n * a.h;
     const int row_begin = split * a.rows_per_split;
     const int row_end = min(total_rows, row_begin + a.rows_per_split);
@@ -164,80 +208,89 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[k][t][v] = 0.f;
 
-    // copy plan of this thread, formed once: per unit its offset inside a P16 row block (halves) and its pixel offset
-    // inside the chunk.  (A first version staged the chunk through registers: 10 global loads + 10 ds_write_b128 per thread
+    // copy plan of this thread, formed once: per unit its offset (in 16-byte units) from the chunk's first pixel in plane
+    // 0 of group 0 of its image, and its pixel offset inside the chunk.  (A first version staged the chunk through registers: 10 global loads + 10 ds_write_b128 per thread
     // and chunk took 2100 + 1700 cycles next to 3840 cycles of MFMA work, with nothing to hide them behind at one wave
     // per SIMD -- measured with MPG_WG_DIAG; the wide LDS stores alone run at a third of the read rate.)
     constexpr int NOPX = 1 << 28;                 // pixel offset of a unit that delivers zeros whatever the chunk
     constexpr int SKIP = -(1 << 28);              // ... of a unit that is not copied at all (pad unit, beyond the image)
+    const int plane_px = a.h * a.w;
     int xg[XU], xpo[XU], dg[DU], dpo[DU];
 #pragma unroll
     for (int i = 0; i < XU; ++i) {
-        const int u = tid + i * 256;
+        const int u = tid + i * WG_THREADS;
         const int rr = u / xupr, off = u % xupr;
-        const int pln = rr / xch, ch = rr % xch;
-        xg[i] = ((a.ci0 + ch) * 2 + pln) * a.wp + off * 8 - 8;
-        xpo[i] = (u >= xunits || off == xupr - 1) ? SKIP : (ch < a.cin ? off * 8 - 8 : NOPX);
+        const int pln = rr / gx, g = a.ci0 / 8 + rr % gx;
+        xg[i] = (g * 2 + pln) * plane_px + off - 8;
+        xpo[i] = (u >= xunits || off >= xpx) ? SKIP : (g < a.x_cg ? off - 8 : NOPX);
     }
 #pragma unroll
     for (int i = 0; i < DU; ++i) {
-        const int u = tid + i * 256;
+        const int u = tid + i * WG_THREADS;
         const int rr = u / dupr, off = u % dupr;
-        const int pln = rr / dch, ch = rr % dch;
-        dg[i] = ((co_base + ch) * 2 + pln) * a.wp + off * 8;
-        dpo[i] = (u >= dunits || off == dupr - 1) ? SKIP : (ch < a.cout ? off * 8 : NOPX);
+        const int pln = rr / gd, g = co_base / 8 + rr % gd;
+        dg[i] = (g * 2 + pln) * plane_px + off;
+        dpo[i] = (u >= dunits || off >= dpx) ? SKIP : (g < a.d_cg ? off : NOPX);
     }
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wave_u = wave;
     // (the copy of a chunk is written in NPART parts so that variants can place them; the CU's address unit takes ~40 cycles
     // per LDS-DMA instruction of this shape: 3000 cycles for the 68 instructions of a chunk, measured)
-    constexpr int NPART = 4;
-    struct ChunkAt { const _Float16* xrow; const _Float16* drow; int x0; bool row_ok; };
-    auto chunk_at = [&](int wi) {
-        const int row = row_begin + wi / chunks_per_row;        // output row b*h + oy
-        const int x0 = (wi % chunks_per_row) * a.chunk;
-        const int oy = row % a.h;
-        const int iy = oy + ky - a.pt;
-        ChunkAt c;
-        c.x0 = x0;
-        c.row_ok = iy >= 0 && iy < a.h;
-        c.xrow = a.xp + (size_t)(row - oy + iy) * a.cin_total * 2 * a.wp + x0;
-        c.drow = a.dp + (size_t)row * a.cout_total * 2 * a.wp + x0;
-        return c;
+    constexpr int NPART = XU + DU;             // one LDS-DMA instruction per part: x pieces first, then the dy pieces
+    // position of the next chunk to copy: image b, output row oy, chunk ci of the row; stepped from chunk to chunk (the
+    // divisions of a position formed from the chunk number were 800 cycles per chunk and wave: hipcc does them on the
+    // vector unit).  Plain scalars, not a struct handed around by reference: that one ended up in scratch memory, and
+    // every copy instruction then waited for a scratch load -- and with it for all the copies in flight.
+    int nb = row_begin / a.h, noy = row_begin % a.h, nci = 0;
+    // source of the chunk at (nb, noy, nci): rows of x and dy, first pixel, and whether the x row exists
+    const char* c_xrow = nullptr;
+    const char* c_drow = nullptr;
+    int c_x0 = 0;
+    bool c_ok = false;
+    auto take_chunk = [&]() {
+        const int iy = noy + ky - a.pt;
+        c_x0 = nci * a.chunk;
+        c_ok = iy >= 0 && iy < a.h;
+        c_xrow = a.xg + (((size_t)nb * a.x_cg * 2) * plane_px + (size_t)iy * a.w + c_x0) * 16;
+        c_drow = a.dg + (((size_t)nb * a.d_cg * 2) * plane_px + (size_t)noy * a.w + c_x0) * 16;
+        if (++nci == chunks_per_row) {
+            nci = 0;
+            if (++noy == a.h) { noy = 0; ++nb; }
+        }
     };
-    auto dma_part = [&](const ChunkAt& c, int buf, auto part_c) {
+    auto dma_part = [&](int buf, auto part_c) {
         constexpr int P = decltype(part_c)::value;
-        const int x0 = c.x0;
-        const bool row_ok = c.row_ok;
-        const _Float16* xrow = c.xrow;
-        const _Float16* drow = c.drow;
-#pragma unroll
-        for (int i = P; i < XU; i += NPART) {
+        const int x0 = c_x0;
+        const bool row_ok = c_ok;
+        const char* xrow = c_xrow;
+        const char* drow = c_drow;
+        if constexpr (P < XU) {
+            constexpr int i = P;
             if (xpo[i] != SKIP) {
                 const int px = x0 + xpo[i];
-                const char* src = (row_ok && px >= 0 && px < a.wp) ? reinterpret_cast<const char*>(xrow + xg[i]) : a.zeros;
+                const char* src = (row_ok && px >= 0 && px < a.w) ? xrow + (ptrdiff_t)xg[i] * 16 : a.zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(xs[buf] + (i * 4 + wave_u) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(xs(buf) + (i * WG_WAVES + wave_u) * 1024),
                                                  16, 0, 0);
             }
         }
-#pragma unroll
-        for (int i = P; i < DU; i += NPART) {
+        if constexpr (P >= XU) {
+            constexpr int i = P - XU;
             if (dpo[i] != SKIP) {
-                const char* src = (row_ok && x0 + dpo[i] < a.wp) ? reinterpret_cast<const char*>(drow + dg[i]) : a.zeros;
+                const char* src = (row_ok && x0 + dpo[i] < a.w) ? drow + (ptrdiff_t)dg[i] * 16 : a.zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(dsm[buf] + (i * 4 + wave_u) * 1024),
+                                                 (__attribute__((address_space(3))) void*)(dsm(buf) + (i * WG_WAVES + wave_u) * 1024),
                                                  16, 0, 0);
             }
         }
     };
 
-    auto dma_parts_from = [&](const ChunkAt& c, int buf, int first) {      // parts first .. NPART-1 (first is wave-uniform)
-        if (first <= 0) dma_part(c, buf, std::integral_constant<int, 0>{});
-        if (first <= 1) dma_part(c, buf, std::integral_constant<int, 1>{});
-        if (first <= 2) dma_part(c, buf, std::integral_constant<int, 2>{});
-        if (first <= 3) dma_part(c, buf, std::integral_constant<int, 3>{});
+    auto dma_parts = [&](int buf, int first, int end) {      // parts first .. end-1 (wave-uniform bounds)
+        static_for_wg<0, NPART>([&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            if (first <= P && P < end) dma_part(buf, pc);
+        });
     };
-    if (nwork > 0) dma_parts_from(chunk_at(0), 0, 0);
+    if (nwork > 0) { take_chunk(); dma_parts(0, 0, NPART); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int ksteps = a.chunk / 16;
@@ -250,74 +303,144 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 #if MPG_WG_DIAG
         const unsigned long long t0 = WG_T();
 #endif
-        // the whole next chunk at once: spreading the LDS-DMA instructions between the MFMA phases was measured SLOWER
-        // (9900 against 9000 cycles per chunk): with one wave per SIMD every instruction stalls the wave while the CU's
-        // address unit works, and the matrix pipe drains each time
-        if (wi + 1 < nwork) dma_parts_from(chunk_at(wi + 1), buf ^ 1, 0);
+        // the whole copy of the next chunk first (see MPG_WG_SPREAD), then the k-steps
+        const bool has_next = wi + 1 < nwork && !(MPG_WG_EXP & 4);
+        if (has_next) take_chunk();
+        const int my_steps = ks < a.ks ? (ksteps - ks + a.ks - 1) / a.ks : 0;
+        int next_part = 0;
+#if !MPG_WG_SPREAD
+        if (has_next) { dma_parts(buf ^ 1, 0, NPART); next_part = NPART; }
+#endif
 #if MPG_WG_DIAG
         const unsigned long long t1 = WG_T();
 #endif
-        const char* xb = xs[buf] + (cit * 32 + r) * a.xrowb + hh * 16;
-        const char* db = dsm[buf] + ((cog * COTW) * 32 + r) * a.drowb + hh * 16;
-        for (int j = ks; j < ksteps && ks < a.ks; j += a.ks) {
-            // 24-pixel window of x per plane: pixels [16j + 8h - 8, 16j + 8h + 16) relative to the chunk start
-            unsigned int win[2][12];
+        // transposed reads: the 16 lanes (lane & 48) own 16 channels = two groups; lane 4q+p of them addresses pixel q,
+        // channels 4p .. 4p+3 of the block and receives 4 pixels of channel (lane & 15).  Rows of 16 k + 4 units put the
+        // four groups a 32-lane half reads 16 banks apart, the pixels 4 banks: no conflicts.
+        const int sub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+        const char* xb = xs(buf) + ((cit * 4 + sub * 2 + (tp >> 1)) * a.xp + 8 * hh + tq) * 16 + (tp & 1) * 8;
+        const char* db = dsm(buf) + ((cog * COTW * 4 + sub * 2 + (tp >> 1)) * a.dp + 8 * hh + tq) * 16 + (tp & 1) * 8;
+        const int xplane = gx * a.xp * 16, dplane = gd * a.dp * 16, dtile = 4 * a.dp * 16;
+        // Per 16-pixel k-step: a 24-pixel window of x per plane -- pixels [16j + 8h - 8, 16j + 8h + 16) relative to the chunk
+        // start -- as 6 transposed reads of 4 pixels, and a dy fragment (8 pixels) per cout tile and plane as two.  The reads
+        // run one product ahead of their MFMAs: in issue order hi window, hi dy | lo dy, lo window, and behind the second
+        // product of a k-step the hi reads of the NEXT k-step, behind the third its lo reads, so that every wait finds its
+        // reads issued 5..10 MFMAs earlier.  (All 16 reads of a k-step in front of its first product, every wave of the block
+        // at the same moment, took 1780 cycles per k-step for 480 of MFMA work: the waves queue at the LDS.)  The last k-step
+        // of the chunk issues its look-ahead reads too, at its own addresses: the waits count them.
+        constexpr int NB = 2 * COTW;
+        const unsigned xa0 = lds_off(xb), da0 = lds_off(db);
+        u32x2 w0[6], w1[6], b0[COTW][2], b1[COTW][2];
+        auto read_hi = [&](u32x2 (&w)[6], u32x2 (&b)[COTW][2], int j) {
+            const unsigned xa = xa0 + j * 256, da = da0 + j * 256;
 #pragma unroll
-            for (int pln = 0; pln < nplane; ++pln) {
+            for (int m = 0; m < 6; ++m) tr_read_at(w[m], xa, m);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(xb + pln * xch * a.xrowb + j * 32 + q * 16);
-                    win[pln][4 * q + 0] = v[0]; win[pln][4 * q + 1] = v[1];
-                    win[pln][4 * q + 2] = v[2]; win[pln][4 * q + 3] = v[3];
-                }
+            for (int t = 0; t < COTW; ++t) {
+                lds_read_tr<0>(b[t][0], da + t * dtile);
+                lds_read_tr<64>(b[t][1], da + t * dtile);
             }
-            half8 bfr[2][COTW];
+        };
+        auto read_lo = [&](u32x2 (&w)[6], u32x2 (&b)[COTW][2], int j) {
+            const unsigned xa = xa0 + xplane + j * 256, da = da0 + dplane + j * 256;
 #pragma unroll
-            for (int pln = 0; pln < nplane; ++pln)
+            for (int t = 0; t < COTW; ++t) {
+                lds_read_tr<0>(b[t][0], da + t * dtile);
+                lds_read_tr<64>(b[t][1], da + t * dtile);
+            }
 #pragma unroll
-                for (int t = 0; t < COTW; ++t)
-                    bfr[pln][t] = *reinterpret_cast<const half8*>(db + pln * dch * a.drowb + t * 32 * a.drowb + j * 32);
-            // the shifted A fragments of all taps first, then the products in product-major order: consecutive MFMAs go
-            // to different accumulators (three back-to-back products into one accumulator wait for each other with one
-            // wave per SIMD)
-            half8 afr[KW][2];
+            for (int m = 0; m < 6; ++m) tr_read_at(w[m], xa, m);
+        };
+        // the KW shifted A fragments of a window: pixels [8 + s, 16 + s), s = kx - pl (|s| <= 3); register q of the window is
+        // w[q / 2][q % 2]; odd shifts through v_alignbit
+        auto shifted = [&](const u32x2 (&w)[6], half8 (&afr)[KW]) {
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
-                // pixels [8 + s, 16 + s) of the window, s = kx - pl (|s| <= 3)
                 const int s = kx - (KW - 1) / 2;
+                u32x4 f;
+                if ((s & 1) == 0) {
+                    const int q = (8 + s) / 2;
 #pragma unroll
-                for (int pln = 0; pln < nplane; ++pln) {
-                    u32x4 f;
-                    if ((s & 1) == 0) {
-                        const int q = (8 + s) / 2;
-                        f[0] = win[pln][q]; f[1] = win[pln][q + 1]; f[2] = win[pln][q + 2]; f[3] = win[pln][q + 3];
-                    } else {
-                        const int q = (7 + s) / 2;
+                    for (int i = 0; i < 4; ++i) f[i] = w[(q + i) / 2][(q + i) % 2];
+                } else {
+                    const int q = (7 + s) / 2;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            f[i] = __builtin_amdgcn_alignbit(win[pln][q + i + 1], win[pln][q + i], 16);
-                    }
-                    afr[kx][pln] = __builtin_bit_cast(half8, f);
+                    for (int i = 0; i < 4; ++i)
+                        f[i] = __builtin_amdgcn_alignbit(w[(q + i + 1) / 2][(q + i + 1) % 2], w[(q + i) / 2][(q + i) % 2], 16);
                 }
+                afr[kx] = __builtin_bit_cast(half8, f);
             }
+        };
+        auto frag_of = [](const u32x2 (&b)[2]) {
+            u32x4 f;
+            f[0] = b[0][0]; f[1] = b[0][1]; f[2] = b[1][0]; f[3] = b[1][1];
+            return __builtin_bit_cast(half8, f);
+        };
+        // one k-step: its hi fragments in (wc, bc), the look-ahead hi reads go to (wn, bn) -- the two sets alternate, so that no
+        // register is copied while its read is still in flight (nothing but the counted waits orders these reads)
+        auto kstep = [&](u32x2 (&wc)[6], u32x2 (&bc)[COTW][2], u32x2 (&wn)[6], u32x2 (&bn)[COTW][2], int j) {
+            auto dma_slot = [&]() {       // the next chunk's copy: one LDS-DMA instruction in front of each product
+                if (has_next && next_part < NPART) {
+                    dma_parts(buf ^ 1, next_part, next_part + 1);
+                    ++next_part;
+                }
+            };
+            dma_slot();
+            const int jn = j + a.ks < ksteps ? j + a.ks : j;
+            half8 ah[KW], bh[COTW];
+            lgkm_wait<(PREC == 3 ? NB + 6 : 0)>();
+#pragma unroll
+            for (int m = 0; m < 6; ++m) tie(wc[m]);
+#pragma unroll
+            for (int t = 0; t < COTW; ++t) { tie(bc[t][0]); tie(bc[t][1]); bh[t] = frag_of(bc[t]); }
+            shifted(wc, ah);
+            // the products in product-major order: consecutive MFMAs go to different accumulators
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
                 for (int t = 0; t < COTW; ++t)
-                    acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][0], bfr[0][t], acc[kx][t], 0, 0, 0);
+                    acc[kx][t] = WG_MFMA(ah[kx], bh[t], acc[kx][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // the products stay in front of the reads and waits behind them
             if (PREC == 3) {
+                half8 bl[COTW], al[KW];
+                dma_slot();
+                lgkm_wait<6>();
+#pragma unroll
+                for (int t = 0; t < COTW; ++t) { tie(b1[t][0]); tie(b1[t][1]); bl[t] = frag_of(b1[t]); }
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
                     for (int t = 0; t < COTW; ++t)
-                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][0], bfr[1][t], acc[kx][t], 0, 0, 0);
+                        acc[kx][t] = WG_MFMA(ah[kx], bl[t], acc[kx][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_hi(wn, bn, jn);
+                dma_slot();
+                lgkm_wait<6 + NB>();
+#pragma unroll
+                for (int m = 0; m < 6; ++m) tie(w1[m]);
+                shifted(w1, al);
 #pragma unroll
                 for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
                     for (int t = 0; t < COTW; ++t)
-                        acc[kx][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[kx][1], bfr[0][t], acc[kx][t], 0, 0, 0);
+                        acc[kx][t] = WG_MFMA(al[kx], bh[t], acc[kx][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_lo(w1, b1, jn);
+            } else {
+                read_hi(wn, bn, jn);
             }
+        };
+        u32x2 w0b[6], b0b[COTW][2];
+        if (my_steps > 0) {
+            read_hi(w0, b0, ks);
+            if (PREC == 3) read_lo(w1, b1, ks);
         }
+        for (int t = 0, j = ks; t < my_steps; t += 2, j += 2 * a.ks) {
+            kstep(w0, b0, w0b, b0b, j);
+            if (t + 1 < my_steps) kstep(w0b, b0b, w0, b0, j + a.ks);
+        }
+        if (my_steps > 0) lgkm_wait<0>();      // the look-ahead reads of the last k-step
+        if (has_next) dma_parts(buf ^ 1, next_part, NPART);     // waves without k-steps, or whatever is left
 #if MPG_WG_DIAG
         const unsigned long long t2a = WG_T();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -339,7 +462,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgArgs a) {
 #endif
 
     // epilogue: D row = (v&3) + 8*(v>>2) + 4*(lane>>5) is the input channel, column lane&31 the output channel
-    const float unscale = a.wscale / (pow2_scale(a.amax[0]) * pow2_scale(a.amax[1]));
+    const float unscale = a.wscale / ((a.x_amax ? pow2_scale(*a.x_amax) : 1.f) * (a.d_amax ? pow2_scale(*a.d_amax) : 1.f));
 #pragma unroll
     for (int kx = 0; kx < KW; ++kx)
 #pragma unroll
@@ -371,11 +494,78 @@ hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes, 
     static int lds_limit[64] = {0};
     hipError_t e = mpg::ensure_dyn_lds((const void*)kern, 160 * 1024, lds_limit);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(blocks * windows), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(blocks * windows), dim3(WG_THREADS), lds_bytes, s, a);
     return hipGetLastError();
 }
 
-inline size_t p16_elems(int n, int h, int w, int c) { return (size_t)n * h * c * 2 * ((w + 7) & ~7); }
+inline size_t g8_bytes(int n, int h, int w, int c) { return (size_t)n * ((c + 7) / 8) * 2 * h * w * 16; }
+
+// all launches of one weight gradient; dw is zeroed first (the row ranges are combined with atomics)
+int wgrad_launches(hipStream_t s, const char* xg, const char* dg, const float* x_amax, const float* d_amax, int n, int h,
+                   int w, int cin, int cout, int kh, int kw, float wscale, int prec, float* dw) {
+    const char* zeros = mpg::zero_page();
+    MPG_REQUIRE(zeros != nullptr, "mpg_conv2d_wgrad: could not allocate the zero page");
+    MPG_REQUIRE((size_t)((cin > cout ? cin : cout) + 7) / 8 * 2 * h * w < (1u << 30), "mpg_conv2d_wgrad: image too large");
+    hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
+    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad: memset");
+    // a wave keeps KW * COTW accumulator tiles of 16 registers, 6 at most beside its fragments (256 registers per wave at two
+    // waves per SIMD; 8 tiles compiled to 3 spilled registers), so a 4- or 5-wide filter row takes 64 output channels per
+    // window (x is then staged twice, from L2)
+    const int co_step = kw >= 4 ? 64 : 128;
+    const bool merged = cout > co_step && cout % co_step == 0;     // equal windows: one launch, windows on grid.y
+    for (int ci0 = 0; ci0 < cin; ci0 += 128)
+        for (int co0 = 0; co0 < (merged ? 1 : cout); co0 += co_step) {
+            WgArgs a;
+            a.xg = xg; a.dg = dg; a.x_amax = x_amax; a.d_amax = d_amax; a.dw = dw; a.zeros = zeros;
+            a.n = n; a.h = h; a.w = w;
+            a.x_cg = (cin + 7) / 8; a.d_cg = (cout + 7) / 8;
+            a.cin_total = cin; a.cout_total = cout; a.ci0 = ci0; a.co0 = co0;
+            a.cin = cin - ci0 < 128 ? cin - ci0 : 128;
+            a.cout = cout - co0 < co_step ? cout - co0 : co_step;
+            a.kh = kh; a.pt = (kh - 1) / 2; a.pl = (kw - 1) / 2;
+            a.wscale = wscale;
+            const int nci = (a.cin + 31) / 32, nco = (a.cout + 31) / 32;
+            a.cit = nci > 2 ? 4 : nci;                           // 1, 2, 4 ci tiles, one per wave
+            const int avail = WG_WAVES / a.cit;                   // waves left for output-channel groups
+            int cog = nco >= 3 ? 4 : nco;                         // 1, 2, 4
+            if (cog > avail) cog = avail;
+            a.cog = cog;
+            const int cotw = (nco + cog - 1) / cog;               // co tiles per wave: 1, 2
+            const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
+            a.ks = WG_WAVES / (a.cit * a.cog);                    // waves left over split the 16-pixel k-steps of a chunk
+            a.chunk = 32 * a.ks < 64 ? 64 : 32 * a.ks;            // fewer barriers per pixel with 64-pixel chunks
+            const int xu = X_UNITS_DMA;
+            const int gx = a.cit * 4, gd = a.cog * cotw * 4;      // channel groups of the LDS images
+            // short rows, and at most xu (x) / D_UNITS_DMA (dy) LDS-DMA instructions per wave in the copy plan
+            auto x_units = [&](int chunk) { return gx * npl * (chunk + 16 + LDS_ROW_PAD); };
+            auto d_units = [&](int chunk) { return gd * npl * (chunk + LDS_ROW_PAD); };
+            while (a.chunk > 32 && (a.chunk / 2 >= w || x_units(a.chunk) > xu * WG_THREADS || d_units(a.chunk) > D_UNITS_DMA * WG_THREADS))
+                a.chunk /= 2;
+            if (a.chunk / 16 < a.ks) a.ks = a.chunk / 16;         // the other waves idle (tiny layers)
+            a.xp = a.chunk + 16 + LDS_ROW_PAD;
+            a.dp = a.chunk + LDS_ROW_PAD;
+            const size_t lds = 2 * ((size_t)x_units(a.chunk) + d_units(a.chunk)) * 16;
+            MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_wgrad: LDS plan %zu bytes", lds);
+            MPG_REQUIRE(x_units(a.chunk) <= xu * WG_THREADS && d_units(a.chunk) <= D_UNITS_DMA * WG_THREADS, "mpg_conv2d_wgrad: copy plan");
+            const int rows = n * h;
+            int want = 1024 / kh;
+            if (want < 1) want = 1;
+            int nsplit = want < rows ? want : rows;
+            a.rows_per_split = (rows + nsplit - 1) / nsplit;
+            a.nsplit = (rows + a.rows_per_split - 1) / a.rows_per_split;
+            const int blocks = ((a.nsplit + 7) / 8) * 8 * kh;
+            const int windows = merged ? cout / co_step : 1;
+            a.windows = windows;
+            hipError_t le = hipErrorInvalidValue;
+#define MPG_WGM(K, C)                                                                        \
+    if (kw == K && cotw == C)                                                                \
+        le = prec == MPG_PREC_F16X3 ? launch<K, C, 3>(s, a, blocks, lds, windows) : launch<K, C, 1>(s, a, blocks, lds, windows)
+            MPG_WGM(1, 1); MPG_WGM(1, 2); MPG_WGM(3, 1); MPG_WGM(3, 2); MPG_WGM(4, 1); MPG_WGM(5, 1);
+#undef MPG_WGM
+            if (le != hipSuccess) return mpg::hip_check(le, "wgrad_mfma_kernel");
+        }
+    MPG_LAUNCH_CHECK("mpg_conv2d_wgrad");
+}
 
 }  // namespace
 
@@ -401,7 +591,26 @@ extern "C" int mpg_absmax(mpg_stream_t stream, const float* x, size_t n, float* 
 
 extern "C" size_t mpg_conv2d_wgrad_mfma_ws_bytes(int n, int h, int w, int cin, int cout) {
     if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1) return 0;
-    return 256 + (p16_elems(n, h, w, cin) + p16_elems(n, h, w, cout)) * sizeof(_Float16);
+    return 256 + g8_bytes(n, h, w, cin) + g8_bytes(n, h, w, cout);
+}
+
+static int wgrad_check(int n, int h, int w, int cin, int cout, int kh, int kw, int prec) {
+    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_wgrad: bad shape");
+    MPG_REQUIRE(kh >= 1 && kh <= 7 && (kw == 1 || kw == 3 || kw == 4 || kw == 5), "mpg_conv2d_wgrad: filter %dx%d not built", kh, kw);
+    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3, "mpg_conv2d_wgrad: prec %d", prec);
+    return MPG_OK;
+}
+
+// both operands already in G8 (the layer's forward input as the convolution kernel read it, and the scaled dy of the
+// data-gradient convolution): no pass over either before the matrix kernel
+extern "C" int mpg_conv2d_wgrad_g8(mpg_stream_t stream, const void* x_g8, int n, int h, int w, int cin, const void* dy_g8, int cout,
+                                   int kh, int kw, float wscale, int prec, const float* x_amax, const float* dy_amax, float* dw) {
+    MPG_REQUIRE(x_g8 && dy_g8 && dw, "mpg_conv2d_wgrad_g8: null pointer");
+    MPG_REQUIRE(((((uintptr_t)x_g8) | ((uintptr_t)dy_g8)) & 15) == 0, "mpg_conv2d_wgrad_g8: operands must be 16-byte aligned");
+    const int rc = wgrad_check(n, h, w, cin, cout, kh, kw, prec);
+    if (rc != MPG_OK) return rc;
+    return wgrad_launches((hipStream_t)stream, (const char*)x_g8, (const char*)dy_g8, x_amax, dy_amax, n, h, w, cin, cout, kh, kw,
+                          wscale, prec, dw);
 }
 
 extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n, int h, int w, int cin,
@@ -409,91 +618,27 @@ extern "C" int mpg_conv2d_wgrad_mfma(mpg_stream_t stream, const float* x, int n,
                                      void* workspace, size_t workspace_bytes, const float* dy_amax, const float* x_amax,
                                      float* dw) {
     MPG_REQUIRE(x && dy && dw && workspace, "mpg_conv2d_wgrad_mfma: null pointer");
-    MPG_REQUIRE(n >= 1 && h >= 1 && w >= 1 && cin >= 1 && cout >= 1, "mpg_conv2d_wgrad_mfma: bad shape");
-    MPG_REQUIRE(kh >= 1 && kh <= 7 && (kw == 1 || kw == 3 || kw == 4 || kw == 5),
-                "mpg_conv2d_wgrad_mfma: filter %dx%d not built", kh, kw);
-    MPG_REQUIRE(prec == MPG_PREC_F16X1 || prec == MPG_PREC_F16X3, "mpg_conv2d_wgrad_mfma: prec %d", prec);
+    const int rc = wgrad_check(n, h, w, cin, cout, kh, kw, prec);
+    if (rc != MPG_OK) return rc;
     MPG_REQUIRE(workspace_bytes >= mpg_conv2d_wgrad_mfma_ws_bytes(n, h, w, cin, cout) &&
                     (((uintptr_t)workspace) & 255) == 0,
                 "mpg_conv2d_wgrad_mfma: workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
-    const char* zeros = mpg::zero_page();
-    MPG_REQUIRE(zeros != nullptr, "mpg_conv2d_wgrad_mfma: could not allocate the zero page");
-    const int wp = (w + 7) & ~7;
     float* amax = (float*)workspace;
-    _Float16* xp = (_Float16*)((char*)workspace + 256);
-    _Float16* dp = xp + p16_elems(n, h, w, cin);
+    char* xg = (char*)workspace + 256;
+    char* dg = xg + g8_bytes(n, h, w, cin);
     // amax[0] / amax[1]: the callers' values where given (one small kernel: device-to-device copies are slower graph
     // nodes than a launch), zero where the reductions below fill them in
     hipLaunchKernelGGL(amax_init_kernel, dim3(1), dim3(64), 0, s, amax, x_amax, dy_amax);
-    hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
-    if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad_mfma: memset");
     const size_t nx = (size_t)n * h * w * cin, nd = (size_t)n * h * w * cout;
     auto am_grid = [](size_t n) { const size_t b = (n + BLK * 16 - 1) / (BLK * 16); return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); };
     if (x_amax == nullptr)       // else: e.g. a forward activation whose scale the caller fixes (no reduction pass over x)
         hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nx)), dim3(BLK), 0, s, x, nx, (unsigned int*)amax);
     if (dy_amax == nullptr)      // else: the caller already has max |dy| (it scales the data gradient with it too)
         hipLaunchKernelGGL(absmax_kernel, dim3(am_grid(nd)), dim3(BLK), 0, s, dy, nd, (unsigned int*)(amax + 1));
-    hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cin + 63) / 64), dim3(256), 0, s, x, h, w, cin, wp,
-                       amax, xp);
-    hipLaunchKernelGGL(to_p16_kernel, dim3(n * h, (w + 63) / 64, (cout + 63) / 64), dim3(256), 0, s, dy, h, w, cout, wp,
-                       amax + 1, dp);
-
-    // a wave keeps KW * COTW accumulator tiles of 16 registers in the 256 AccVGPRs: 16 tiles at most, so a
-    // 5-wide filter row takes 64 output channels per launch (x is then staged twice, from L2)
-    const int co_step = kw >= 5 ? 64 : 128;
-    const bool merged = cout > co_step && cout % co_step == 0;     // equal windows: one launch, windows on grid.y
-    for (int ci0 = 0; ci0 < cin; ci0 += 128)
-        for (int co0 = 0; co0 < (merged ? 1 : cout); co0 += co_step) {
-            WgArgs a;
-            a.xp = xp; a.dp = dp; a.amax = amax; a.dw = dw; a.zeros = zeros;
-            a.n = n; a.h = h; a.w = w; a.wp = wp;
-            a.cin_total = cin; a.cout_total = cout; a.ci0 = ci0; a.co0 = co0;
-            a.cin = cin - ci0 < 128 ? cin - ci0 : 128;
-            a.cout = cout - co0 < co_step ? cout - co0 : co_step;
-            a.kh = kh; a.pt = (kh - 1) / 2; a.pl = (kw - 1) / 2;
-            a.wscale = wscale;
-            const int nci = (a.cin + 31) / 32, nco = (a.cout + 31) / 32;
-            a.cit = nci > 2 ? 4 : nci;                           // 1, 2, 4 ci tiles, one per wave
-            const int avail = 4 / a.cit;                          // waves left for output-channel groups
-            int cog = nco >= 3 ? 4 : nco;                         // 1, 2, 4
-            if (cog > avail) cog = avail;
-            a.cog = cog;
-            int cotw = (nco + cog - 1) / cog;                     // co tiles per wave: 1, 2, 4
-            if (cotw == 3) cotw = 4;
-            const int npl = prec == MPG_PREC_F16X3 ? 2 : 1;
-            a.ks = 4 / (a.cit * a.cog);                           // waves left over split the 16-pixel k-steps of a chunk
-            a.chunk = 32 * a.ks < 64 ? 64 : 32 * a.ks;            // fewer barriers per pixel with 64-pixel chunks
-            const int xu = x_units_dma(kw, cotw);
-            // short rows, and at most xu (x) / D_UNITS_DMA (dy) LDS-DMA instructions per wave in the copy plan
-            while (a.chunk > 32 && (a.chunk / 2 >= wp || a.cit * 32 * npl * ((a.chunk + 16) / 8 + 1) > xu * 256 ||
-                                    a.cog * cotw * 32 * npl * (a.chunk / 8 + 1) > D_UNITS_DMA * 256))
-                a.chunk /= 2;
-            if (a.chunk / 16 < a.ks) a.ks = a.chunk / 16;         // the other waves idle (tiny layers)
-            a.xrowb = (a.chunk + 16) * 2 + 16;
-            a.drowb = a.chunk * 2 + 16;
-            const size_t lds = 2 * ((size_t)a.cit * 32 * npl * a.xrowb + (size_t)a.cog * cotw * 32 * npl * a.drowb);
-            MPG_REQUIRE(lds <= 160 * 1024, "mpg_conv2d_wgrad_mfma: LDS plan %zu bytes", lds);
-            MPG_REQUIRE(a.cit * 32 * npl * ((a.chunk + 16) / 8 + 1) <= xu * 256 &&
-                            a.cog * cotw * 32 * npl * (a.chunk / 8 + 1) <= D_UNITS_DMA * 256,
-                        "mpg_conv2d_wgrad_mfma: copy plan");
-            const int rows = n * h;
-            int want = 1024 / kh;
-            if (want < 1) want = 1;
-            int nsplit = want < rows ? want : rows;
-            a.rows_per_split = (rows + nsplit - 1) / nsplit;
-            a.nsplit = (rows + a.rows_per_split - 1) / a.rows_per_split;
-            const int blocks = ((a.nsplit + 7) / 8) * 8 * kh;
-            const int windows = merged ? cout / co_step : 1;
-            a.windows = windows;
-            hipError_t le = hipErrorInvalidValue;
-#define MPG_WGM(K, C)                                                                        \
-    if (kw == K && cotw == C)                                                                \
-        le = prec == MPG_PREC_F16X3 ? launch<K, C, 3>(s, a, blocks, lds, windows) : launch<K, C, 1>(s, a, blocks, lds, windows)
-            MPG_WGM(1, 1); MPG_WGM(1, 2); MPG_WGM(1, 4); MPG_WGM(3, 1); MPG_WGM(3, 2); MPG_WGM(3, 4);
-            MPG_WGM(4, 1); MPG_WGM(4, 2); MPG_WGM(4, 4); MPG_WGM(5, 1); MPG_WGM(5, 2);
-#undef MPG_WGM
-            if (le != hipSuccess) return mpg::hip_check(le, "wgrad_mfma_kernel");
-        }
-    MPG_LAUNCH_CHECK("mpg_conv2d_wgrad_mfma");
+    int e = mpg_f32_to_g8_scaled(stream, x, n, h, w, cin, 0, cin, MPG_G8_F16, amax, xg);
+    if (e != MPG_OK) return e;
+    e = mpg_f32_to_g8_scaled(stream, dy, n, h, w, cout, 0, cout, MPG_G8_F16, amax + 1, dg);
+    if (e != MPG_OK) return e;
+    return wgrad_launches(s, xg, dg, amax, amax + 1, n, h, w, cin, cout, kh, kw, wscale, prec, dw);
 }

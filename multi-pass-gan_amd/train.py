@@ -27,10 +27,11 @@ def _mfma_ok(kh, kw, width, stride):
     return stride == (1, 1) and kh <= 7 and kw <= 7 and width <= 512
 
 
-def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None):
+def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None, keep=None):
     """conv2d_SAME(x, w * wscale) [+ bias, act] on the MFMA kernel, output channels in chunks of 128.
     rescale: x is a gradient (1e-4 .. 1e-8 in magnitude, below the fp16 normal range): it is split into
-    fp16 hi/lo after a power-of-two scaling by its absolute maximum, and the sum is scaled back in the epilogue"""
+    fp16 hi/lo after a power-of-two scaling by its absolute maximum, and the sum is scaled back in the epilogue.
+    keep: a list that receives the G8 form of x the kernel read (the weight gradient reads the same tensor)"""
     cout = w.shape[3]
     outs = []
     if not rescale:
@@ -44,6 +45,8 @@ def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, resc
         pk = ops.pack_conv_weights(wc, wscale=wscale, prec=prec)
         bc = None if bias is None else (bias if (c0 == 0 and c1 == cout) else bias[c0:c1].contiguous())
         seg = ops.Segment(x, pk, pad_hi=pad_hi)
+        if len(outs) == 0 and keep is not None:
+            keep.append(seg.x)
         if len(outs) == 0 and c1 < cout and isinstance(x, torch.Tensor):
             x = seg.x                       # reuse the G8 conversion for the other chunks
         outs.append(ops.conv2d_fused([seg], (seg.x.h, seg.x.w), bias=bc, act=act, leak=leak, in_amax=amax))
@@ -59,14 +62,17 @@ class ConvLayerFn(torch.autograd.Function):
         stride, wscale, act, leak = cfg["stride"], cfg["wscale"], cfg["act"], cfg["leak"]
         kh, kw, cin, cout = w.shape
         x = x.contiguous()
+        x_g8 = None
         bn = gamma is not None
         conv_act = None if bn else act
         if cfg.get("fc"):
             lin = train_ops.fc_forward(x.reshape(x.shape[0], cin), w.detach().reshape(cin, cout), wscale, b, conv_act,
                                        leak).reshape(x.shape[0], 1, 1, cout)
         elif _mfma_ok(kh, kw, cout, stride):
+            keep = [] if (ctx.needs_input_grad[1] and train_ops.wgrad_mfma_ok(kh, kw, stride) and cfg.get("wgrad_mfma", True)) else None
             lin = _mfma_conv(x, w.detach().contiguous(), wscale, cfg["prec"], b.detach() if b is not None else None,
-                             conv_act, leak)
+                             conv_act, leak, keep=keep)
+            x_g8 = keep[0] if keep else None
         else:
             lin = ops.conv2d_direct(x, w.detach().contiguous(), stride, wscale, None, b, conv_act, leak)
         if bn:
@@ -78,12 +84,14 @@ class ConvLayerFn(torch.autograd.Function):
             y = lin
             ctx.save_for_backward(x, w, y)
         ctx.cfg, ctx.bn, ctx.has_bias = cfg, bn, b is not None
+        ctx.x_g8 = x_g8                      # the forward input as the kernel read it (hi/lo fp16, unscaled): the weight gradient's operand
         return y
 
     @staticmethod
     def backward(ctx, dy):
         cfg = ctx.cfg
         stride, wscale, act, leak = cfg["stride"], cfg["wscale"], cfg["act"], cfg["leak"]
+        x_g8, ctx.x_g8 = ctx.x_g8, None
         if ctx.bn:
             x, w, lin, mean, var, gamma, y = ctx.saved_tensors
         else:
@@ -108,8 +116,17 @@ class ConvLayerFn(torch.autograd.Function):
         dw = None
         if need_amax and d_amax is None:
             d_amax = ops.absmax(d)                                                      # shared by both gradients
+        wgrad_mm = ctx.needs_input_grad[1] and train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and \
+            cfg.get("wgrad_mfma", True)
+        dgrad_mm = ctx.needs_input_grad[0] and _mfma_ok(kh, kw, cin, stride) and not cfg.get("fc")
+        d_g8 = None
+        if x_g8 is not None and wgrad_mm:
+            # one scaled hi/lo conversion of d feeds both gradient kernels; x comes from the forward launch
+            d_g8 = ops.to_g8(d, 0, cout, ops.flavour_for(cfg["prec"]), amax=d_amax)
         if ctx.needs_input_grad[1]:
-            if train_ops.wgrad_mfma_ok(kh, kw, stride) and not cfg.get("fc") and cfg.get("wgrad_mfma", True):
+            if d_g8 is not None:
+                dw = train_ops.conv2d_wgrad_g8(x_g8, d_g8, kh, kw, wscale, cfg["prec"], None, d_amax)
+            elif wgrad_mm:
                 # x is the layer's forward input (an activation): split unscaled, no abs-max pass over it
                 dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax,
                                                  train_ops.unit_amax(x.device))
@@ -117,9 +134,9 @@ class ConvLayerFn(torch.autograd.Function):
                 dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale)
         dx = None
         if ctx.needs_input_grad[0]:
-            if _mfma_ok(kh, kw, cin, stride) and not cfg.get("fc"):
+            if dgrad_mm:
                 wt = w.detach().flip(0, 1).permute(0, 1, 3, 2).contiguous()      # [kh,kw,cout,cin], taps mirrored
-                dx = _mfma_conv(d, wt, wscale, cfg["prec"], pad_hi=1, rescale=True, amax=d_amax)
+                dx = _mfma_conv(d if d_g8 is None else d_g8, wt, wscale, cfg["prec"], pad_hi=1, rescale=True, amax=d_amax)
             else:
                 dx = train_ops.conv2d_dgrad(d, w.detach(), (x.shape[1], x.shape[2]), stride, wscale)
         return dx, dw, db, dgamma, dbeta, None

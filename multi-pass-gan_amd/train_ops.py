@@ -57,6 +57,18 @@ def conv2d_wgrad_mfma(x, dy, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, dy_amax=N
     return dw
 
 
+def conv2d_wgrad_g8(xg, dg, kh, kw, wscale=1.0, prec=_lib.PREC_F16X3, x_amax=None, dy_amax=None):
+    """the same weight gradient from G8 operands (ops.G8): the forward input as the convolution read it and the scaled
+    dy of the data-gradient convolution; x_amax / dy_amax = the scalars they were scaled with (mpg_conv2d_wgrad_g8)"""
+    lib = _lib.load()
+    if (xg.n, xg.h, xg.w) != (dg.n, dg.h, dg.w):
+        raise _lib.MpgError("conv2d_wgrad_g8: dy %s does not match x %s" % ((dg.n, dg.h, dg.w), (xg.n, xg.h, xg.w)))
+    dw = torch.empty((kh, kw, xg.c, dg.c), dtype=torch.float32, device=xg.buf.device)
+    _lib.check(lib.mpg_conv2d_wgrad_g8(_stream(), _ptr(xg.buf), xg.n, xg.h, xg.w, xg.c, _ptr(dg.buf), dg.c, kh, kw,
+                                       float(wscale), prec, _ptr(x_amax), _ptr(dy_amax), _ptr(dw)), "mpg_conv2d_wgrad_g8")
+    return dw
+
+
 def conv2d_dgrad(dy, w_hwio, in_hw, stride=(1, 1), wscale=1.0):
     """dL/dx of y = conv2d_SAME(x, W * wscale) for x of spatial size in_hw."""
     lib = _lib.load()

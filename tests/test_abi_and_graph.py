@@ -224,7 +224,10 @@ def test_no_packed_fp32_valu(mpg):
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
             body = m.group(1)
-        elif body and "conv_mfma" in body and "scratch_" in line:
+        elif body and ("conv_mfma" in body or "wgrad_mfma" in body) and "scratch_" in line:
+            # (in the weight-gradient kernel a scratch load in front of an LDS-DMA instruction waits for every copy in
+            # flight: a two-entry pointer table indexed at run time cost 50 % there, profiles/r03/wgrad_variants.md)
             spills[body] = spills.get(body, 0) + 1
-    assert not spills, "scratch traffic in the convolution kernels: %s" % spills
+    assert not spills, "scratch traffic in the matrix-core kernels: %s" % spills
+    assert "ds_read_b64_tr_b16" in asm                          # the weight gradient reads G8 rows through the transposing LDS read
     assert len(set(re.findall(r"<(\S*conv_mfma_f6_kernel\S*)>:", asm))) == 4

@@ -105,6 +105,24 @@ def test_conv_wgrad_mfma(case, prec):
     assert rel(dw2.cpu().numpy(), dw_ref) < (2e-6 if prec == 3 else 2e-3)
 
 
+@pytest.mark.parametrize("prec", [3, 1])
+@pytest.mark.parametrize("case", WG_MFMA_CASES)
+def test_conv_wgrad_g8(case, prec):
+    """the same kernel fed the G8 tensors a training step already holds (forward input unscaled, dy scaled by its maximum):
+    bit-identical to the fp32 entry, which converts to the same G8 inside its workspace"""
+    from mpgan_amd import ops, train_ops
+    n, h, w, cin, cout, k = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31 + 1)
+    x = dev(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    dy = dev((rng.standard_normal((n, h, w, cout)) * 1e-6).astype(np.float32))
+    wscale = float(np.float32(math.sqrt(2.0) / math.sqrt(k * k * cin)))
+    am = ops.absmax(dy)
+    ref = train_ops.conv2d_wgrad_mfma(x, dy, k, k, wscale, prec, am, train_ops.unit_amax(dy.device))
+    got = train_ops.conv2d_wgrad_g8(ops.to_g8(x), ops.to_g8(dy, amax=am), k, k, wscale, prec, None, am)
+    # the row ranges are combined with fp32 atomics in launch order: equal up to that reordering
+    assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
 def test_conv_wgrad_mfma_zero_and_constant():
     from mpgan_amd import train_ops
     x = np.ones((1, 8, 8, 3), np.float32)
@@ -254,7 +272,7 @@ def test_gan4x_losses_and_gradients(C, bn):
     rd = TR.grads(Lr["disc_loss"], p, "d_")
     rg = TR.grads(Lr["gen_loss_complete"], p, "g_")
     assert sorted(rd) == tr.opt_d.names and sorted(rg) == tr.opt_g.names
-    worst = 0.0
+    worst, off = 0.0, []
     for names, got, want in ((tr.opt_d.names, gd, rd), (tr.opt_g.names, gg, rg)):
         tot_d = tot_r = 0.0
         for nme, g in zip(names, got):
@@ -266,10 +284,12 @@ def test_gan4x_losses_and_gradients(C, bn):
                 continue
             r = rel(gnp, w)
             worst = max(worst, r)
-            assert r < 1e-3, (nme, r)
+            if r >= 1e-4:
+                off.append((nme, float("%.3g" % r)))
             tot_d += float(((gnp - w) ** 2).sum())
             tot_r += float((w ** 2).sum())
-        assert math.sqrt(tot_d / tot_r) < 2e-4
+        assert math.sqrt(tot_d / tot_r) < 2e-4, off
+    assert worst < 1e-3, off
     print("worst per-tensor gradient error", worst)
 
 

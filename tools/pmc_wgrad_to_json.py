@@ -16,21 +16,22 @@ def table(d, counter):
     return {k: (sum(v.values()), len(v)) for k, v in by.items()}
 
 f, w = table("pmc_wgrad_fetch", "FETCH_SIZE"), table("pmc_wgrad_write", "WRITE_SIZE")
-out = {"call": "mpg_conv2d_wgrad_mfma as the training step issues it: 5x5 128->128, 16 tiles of 256^2 (x, dy fp32 NHWC 512 MiB each), "
-               "MPG_PREC_F16X3, max |dy| handed in, x split unscaled",
+out = {"call": "the weight gradient as the training step issues it: 5x5 128->128, 16 tiles of 256^2; x = the forward launch's G8 operand "
+               "(512 MiB, no pass of its own), dy fp32 NHWC 512 MiB -> G8 scaled by max |dy| (one conversion shared with the data "
+               "gradient, listed), mpg_conv2d_wgrad_g8 MPG_PREC_F16X3",
        "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/roofline_probe_wgrad.py %d ; same with "
                   "--pmc WRITE_SIZE (separate passes); summarised by tools/pmc_wgrad_to_json.py" % calls,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> doubled; WRITE_SIZE as counted",
        "per_kernel_per_call": {}, "calls": calls}
 tot = 0.0
 for k in sorted(set(f) | set(w)):
-    if not any(t in k for t in ("absmax", "to_p16", "wgrad_mfma")):
+    if not any(t in k for t in ("absmax", "to_g8", "wgrad_mfma")):
         continue
     rd = f.get(k, (0, 0))[0] * 1024 * 2 / calls
     wr = w.get(k, (0, 0))[0] * 1024 / calls
     out["per_kernel_per_call"][k] = {"launches_per_call": f.get(k, w.get(k))[1] / calls, "hbm_read_bytes": rd, "hbm_write_bytes": wr}
     tot += rd + wr
 out["hbm_bytes_per_call"] = tot
-out["algorithmic_bytes_per_call"] = {"x_fp32": 536870912, "dy_fp32": 536870912, "dw": 1638400}
+out["algorithmic_bytes_per_call"] = {"x_g8": 536870912, "dy_g8": 536870912, "dw": 1638400}
 json.dump(out, open(dst + "/roofline_pmc_wgrad.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:1800])

@@ -1,4 +1,4 @@
-"""diagnostic (library built with -DMPG_WG_DIAG=1): where the waves of wgrad_mfma_kernel<5,2,3> spend their cycles"""
+"""diagnostic (library built with -DMPG_WG_DIAG=1): where the waves of wgrad_mfma_kernel<5,1,3> spend their cycles"""
 import ctypes, os, sys
 sys.path.insert(0, ".")
 import torch
@@ -11,9 +11,10 @@ dy = torch.randn((16, 256, 256, 128), device=dev, generator=g) * 1e-4
 da, xa = ops.absmax(dy), train_ops.unit_amax(x.device)
 L = ctypes.CDLL(os.environ["MPGAN_LIB_OVERRIDE"])
 buf = (ctypes.c_ulonglong * 8)()
-train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3, da, xa); torch.cuda.synchronize()
+xg, dg = ops.to_g8(x), ops.to_g8(dy, amax=da)
+train_ops.conv2d_wgrad_g8(xg, dg, 5, 5, 0.025, 3, None, da); torch.cuda.synchronize()
 L.mpg_debug_wg_diag(buf, 1)
-train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3, da, xa); torch.cuda.synchronize()
+train_ops.conv2d_wgrad_g8(xg, dg, 5, 5, 0.025, 3, None, da); torch.cuda.synchronize()
 L.mpg_debug_wg_diag(buf, 1)
 n = buf[6]
 print("waves sampled %d, chunks per wave %.1f" % (n, buf[7] / n))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launches the dominant kernel of the training benches (matrix-core weight gradient of a 5x5 128->128 conv on 16
-tiles of 256^2: abs-max + P16 rewrite + wgrad_mfma_kernel<5,2,3> x2) a few times; run under
+tiles of 256^2: the scaled G8 conversion of dy that the data gradient shares + wgrad_mfma_kernel<5,2,3>) a few times; run under
 `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) to get the HBM traffic per kernel."""
 import os
 import sys
@@ -22,8 +22,13 @@ standalone = "--standalone" in sys.argv
 from mpgan_amd import ops
 dy_amax = None if standalone else ops.absmax(dy)
 x_amax = None if standalone else train_ops.unit_amax(x.device)
+xg = None if standalone else ops.to_g8(x)          # the forward launch's operand, kept for the backward pass
 torch.cuda.synchronize()
 for _ in range(iters):
-    train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3, dy_amax, x_amax)
+    if standalone:
+        train_ops.conv2d_wgrad_mfma(x, dy, 5, 5, 0.025, 3, dy_amax, x_amax)
+    else:
+        dg = ops.to_g8(dy, amax=dy_amax)           # shared with the data-gradient convolution
+        train_ops.conv2d_wgrad_g8(xg, dg, 5, 5, 0.025, 3, None, dy_amax)
 torch.cuda.synchronize()
 print("done")
