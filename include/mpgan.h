@@ -239,6 +239,15 @@ int mpg_volume_transpose(mpg_stream_t stream, const float* v, int d0, int d1, in
 int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_total, size_t hw, int c,
                      int s_off, int s_cnt, float* out);
 
+/* Channel marshalling between the passes (multipassGAN-4x.py:278-283, 1095-1119: the velocity channels are cut out of the
+ * low-res array, scaled by the upres factor and the velocity scale, and concatenated behind the density slices of the
+ * previous pass): out[p][j] = (s[p][map[j]] * scale[j]) * scale2[j], where s is the channel-wise concatenation of
+ * a [npix, ca] and b [npix, cb] (b may be NULL with cb = 0); map, scale and scale2 are HOST arrays of
+ * cout <= MPG_GATHER_MAX_C entries (a NULL scale = all ones; two factors because the reference multiplies twice). */
+#define MPG_GATHER_MAX_C 8
+int mpg_channel_gather(mpg_stream_t stream, const float* a, int ca, const float* b, int cb, size_t npix,
+                       const int* map, const float* scale, const float* scale2, int cout, float* out);
+
 /* out[i] = v[i] < cutoff ? 0 : v[i]   (multipassGAN-4x.py:1156-1157) */
 int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out);
 

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "mpg_volume_transpose": (_I, [_P, _P, _I, _I, _I, _I, ctypes.POINTER(_I), ctypes.POINTER(_I), _F, _P]),
     "mpg_add_adjacent": (_I, [_P, _P, _I, _Z, _I, _I, _I, _P]),
     "mpg_cutoff": (_I, [_P, _P, _Z, _F, _P]),
+    "mpg_channel_gather": (_I, [_P, _P, _I, _P, _I, _Z, _P, _P, _P, _I, _P]),
     "mpg_conv2d_transpose": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P, _I, _F, _P]),
     "mpg_depth_to_space": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     # training step

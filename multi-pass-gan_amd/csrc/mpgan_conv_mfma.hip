@@ -47,6 +47,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_DIAG6
 #define MPG_DIAG6 0
 #endif
+//   MPG_W0 0        the weight planes of correction step 0 are read at the head of the correction phase, not in front of the
+//                   last fp16 group
+#ifndef MPG_W0
+#define MPG_W0 1
+#endif
 //   MPG_ALT 1       experiment, off: the second half of the waves of an 8-wave block runs a stage's correction steps BEFORE its
 //                   fp16 groups (complementary phases on a SIMD).  As compiled the corrections-first order keeps 265 spilled
 //                   registers at four cout tiles (profiles/r03/kloop_variants.md): not measured on the hardware
@@ -67,6 +72,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #else
 #define MPG_STAMP(v)
 #endif
+// the a_hi correction step (0 .. NT-1) behind whose MFMAs the a_lo codes of tile row pt are made
+constexpr int lo_step(int pt, int nt, int ptn) {
+    const int s = nt - ptn + pt - 1;
+    return s < 0 ? 0 : (s > nt - 1 ? nt - 1 : s);
+}
 constexpr int TW = 32;              // tile cols == MFMA N dimension
 constexpr int TAPOFF_BYTES = 1024;  // 256 tap offsets
 
@@ -852,9 +862,23 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
             constexpr int HALF = G16 / 2;
             constexpr int IPG = (MAXI + HALF - 1) / HALF;    // image pieces per group (first half of the groups)
             constexpr int WPG = (NI + HALF - 1) / HALF;      // weight pieces per group (second half)
+            // bf6 weight planes of the correction steps: step k < NT reads w_lo6[k], step k >= NT w_hi6[k - NT]
+            constexpr int KS6 = 2 * NT;                            // correction steps
+            constexpr int WD = MPG_WD < KS6 - 1 ? MPG_WD : KS6 - 1;
+            v4i wq[WD + 1][2];
+            auto read_w6 = [&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int off = WF16 + (k < NT ? WF6 + k * 2048 : (k - NT) * 2048);
+                ds_read16<off>(wq[k % (WD + 1)][0], a_base);
+                ds_read16<off + 1024>(wq[k % (WD + 1)][1], a_base);
+            };
             // ---- the fp16 product: G16 groups of PT MFMAs ----
             auto fp16_phase = [&](auto mk) {
                 constexpr bool MAKE_HI6 = decltype(mk)::value != 0;
+                // fp16 groups first, corrections behind them: the weight planes of correction step 0 are read in front of
+                // the last group (the correction phase then starts on operands that are there: its head was ~200 cycles of
+                // LDS latency, and the younger wave of a SIMD runs that phase alone)
+                constexpr bool W0_AHEAD = MAKE_HI6 && MPG_W0;
                 static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
                 static_for<0, G16>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
@@ -871,7 +895,8 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                         });
                     }
                     if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
-                    lgkm_wait<kx_allowed(g, NT, PT, AH)>();        // reads issued behind group g's own
+                    if constexpr (W0_AHEAD && g == G16 - 1) read_w6(std::integral_constant<int, 0>{});
+                    lgkm_wait<kx_allowed(g, NT, PT, AH) + (W0_AHEAD && g == G16 - 1 ? 2 : 0)>();   // reads issued behind group g's own
                     if constexpr (g == 0 && MAKE_HI6) { MPG_STAMP(ts1); }
                     tie(aq[g % (AH + 1)]);
                     if constexpr (nt == 0)
@@ -891,18 +916,10 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
             // ---- the two bf6 corrections: step k < NT is w_lo6[k] x a_hi6, step k >= NT is w_hi6[k - NT] x a_lo6 ----
             // LDS reads in order: W(0), the a_lo fragments (into the registers of the a_hi ones, which the conversions
             // above have consumed), W(1) .. W(WD), then W(k + WD) ahead of step k.
-            auto bf6_phase = [&]() {
+            auto bf6_phase = [&](auto w0c) {
+            constexpr bool W0_DONE = decltype(w0c)::value != 0;    // W(0) was read in front of the last fp16 group
 #if !(MPG_DIAG6 & 1)
             constexpr int PB = PT;                                 // all a_lo fragments at once: they land in the a_hi registers
-            constexpr int KS6 = 2 * NT;                            // correction steps
-            constexpr int WD = MPG_WD < KS6 - 1 ? MPG_WD : KS6 - 1;
-            v4i wq[WD + 1][2];
-            auto read_w6 = [&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                constexpr int off = WF16 + (k < NT ? WF6 + k * 2048 : (k - NT) * 2048);
-                ds_read16<off>(wq[k % (WD + 1)][0], a_base);
-                ds_read16<off + 1024>(wq[k % (WD + 1)][1], a_base);
-            };
             auto read_bl = [&](auto pc) {
                 constexpr int pt = decltype(pc)::value;
                 static_for<0, 4>([&](auto jc) {
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 lo6[pt] = bf6_of(cat32(bh[pt][0], bh[pt][1], bh[pt][2], bh[pt][3]), e16[pt] + 97);
 #endif
             };
-            read_w6(std::integral_constant<int, 0>{});
+            if constexpr (!W0_DONE) read_w6(std::integral_constant<int, 0>{});
             static_for<0, PB>([&](auto pc) { read_bl(pc); });
             static_for<1, WD + 1>([&](auto kc) { read_w6(kc); });
             static_for<0, KS6>([&](auto kc) {
@@ -931,14 +948,6 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 lgkm_wait<(k == 0 ? 4 * PB : 0) + 2 * ahead>();
                 tie(wq[k % (WD + 1)][0]);
                 tie(wq[k % (WD + 1)][1]);
-                if constexpr (k == 1) {
-                    static_for<0, PB>([&](auto pc) { make_lo6(pc); });
-                    if constexpr (PT > PB) {           // four tile rows per wave (one cout tile): the other two, exposed
-                        static_for<PB, PT>([&](auto pc) { read_bl(pc); });
-                        lgkm_wait<0>();
-                        static_for<PB, PT>([&](auto pc) { make_lo6(pc); });
-                    }
-                }
                 const v8i w6 = __builtin_shufflevector(wq[k % (WD + 1)][0], wq[k % (WD + 1)][1], 0, 1, 2, 3, 4, 5, 6, 7);
                 static_for<0, PT>([&](auto pc) {
                     constexpr int pt = decltype(pc)::value;
@@ -947,6 +956,15 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                     else
                         acc[pt][k - NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w6, lo6[pt], acc[pt][k - NT], BF6, BF6, 0, w6[6], 1, sb[pt]);
                 });
+                // the a_lo codes of tile row pt (VALU: block maximum, scale, 32-value conversion) behind the MFMAs of the a_hi
+                // step lo_step(pt), as late as still finishes in front of the first a_lo step NT: the conversions of the
+                // rows run under the matrix work of different steps instead of in one piece in front of step 1
+                if constexpr (k < NT) {
+                    if constexpr (k == 0 && lo_step(0, NT, PT) == 0) lgkm_wait<2 * ahead>();     // the a_lo fragments are there
+                    static_for<0, PT>([&](auto pc) {
+                        if constexpr (lo_step(decltype(pc)::value, NT, PT) == k) make_lo6(pc);
+                    });
+                }
             });
 #else
             asm volatile("" ::"v"(hi6[0]), "v"(sb[0]), "v"(e16[0]));
@@ -971,13 +989,13 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                     make_hi6(pc);
                 });
                 MPG_STAMP(ts1);
-                bf6_phase();
+                bf6_phase(std::integral_constant<int, 0>{});
                 MPG_STAMP(ts2);
                 fp16_phase(std::integral_constant<int, 0>{});
             } else {
                 fp16_phase(std::integral_constant<int, 1>{});
                 MPG_STAMP(ts2);
-                bf6_phase();
+                bf6_phase(std::integral_constant<int, MPG_W0>{});
             }
             MPG_STAMP(ts3);
         }

@@ -758,6 +758,41 @@ extern "C" int mpg_add_adjacent(mpg_stream_t stream, const float* in, int s_tota
     MPG_LAUNCH_CHECK("add_adjacent_kernel");
 }
 
+// out[p][j] = (src_j[p] * scale[j]) * scale2[j]: channel j of the output is channel map[j] of a (map[j] < ca) or map[j] - ca
+// of b; two factors applied one after the other, as the reference scales the velocities twice (4x.py:278, 283)
+struct GatherArgs { int map[MPG_GATHER_MAX_C]; float scale[MPG_GATHER_MAX_C]; float scale2[MPG_GATHER_MAX_C]; };
+
+__global__ void channel_gather_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb, size_t npix,
+                                      int cout, GatherArgs g, float* __restrict__ out) {
+    const size_t total = npix * cout;
+    for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < total; i += (size_t)gridDim.x * BLK) {
+        const size_t p = i / cout;
+        const int j = (int)(i - p * cout);
+        const int m = g.map[j];
+        const float v = m < ca ? a[p * ca + m] : b[p * cb + (m - ca)];
+        out[i] = (v * g.scale[j]) * g.scale2[j];
+    }
+}
+
+extern "C" int mpg_channel_gather(mpg_stream_t stream, const float* a, int ca, const float* b, int cb, size_t npix,
+                                  const int* map, const float* scale, const float* scale2, int cout, float* out) {
+    MPG_REQUIRE(a && map && out, "mpg_channel_gather: null pointer");
+    MPG_REQUIRE(ca >= 1 && cb >= 0 && (cb == 0 || b != nullptr) && cout >= 1 && cout <= MPG_GATHER_MAX_C,
+                "mpg_channel_gather: bad channel counts %d + %d -> %d", ca, cb, cout);
+    GatherArgs g;
+    for (int j = 0; j < MPG_GATHER_MAX_C; ++j) {
+        g.map[j] = j < cout ? map[j] : 0;
+        g.scale[j] = (j < cout && scale) ? scale[j] : 1.f;
+        g.scale2[j] = (j < cout && scale2) ? scale2[j] : 1.f;
+        MPG_REQUIRE(g.map[j] >= 0 && g.map[j] < ca + cb, "mpg_channel_gather: map[%d] = %d outside %d + %d channels", j, g.map[j], ca, cb);
+    }
+    if (npix == 0) return MPG_OK;
+    size_t blocks = (npix * cout + BLK - 1) / BLK;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(channel_gather_kernel, dim3((unsigned)blocks), dim3(BLK), 0, (hipStream_t)stream, a, ca, b, cb, npix, cout, g, out);
+    MPG_LAUNCH_CHECK("channel_gather_kernel");
+}
+
 extern "C" int mpg_cutoff(mpg_stream_t stream, const float* v, size_t n, float cutoff, float* out) {
     MPG_REQUIRE(v && out, "mpg_cutoff: null pointer");
     if (n == 0) return MPG_OK;

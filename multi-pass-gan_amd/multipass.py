@@ -145,12 +145,13 @@ class Generator(object):
         g._src_version = self.sess.vars.version
         return g
 
-    def __call__(self, x, y=None):
+    def __call__(self, x, y=None, out=None):
+        """out: where the [n, high, high] result goes (a slice of the pass's volume), else a new tensor"""
         n = x.shape[0]
         feeds = {self.x: x.reshape(n, -1)}
         if self.y is not None:
             feeds[self.y] = y.reshape(n, -1)
-        return self.sess.run_device(self.sampler, feeds).reshape(n, self.high, self.high)
+        return self.sess.run_device(self.sampler, feeds, out=out).reshape(n, self.high, self.high)
 
 
 # HIP streams the slice batches of one pass are dealt to (the batches are independent).  1 = the plain loop.
@@ -168,27 +169,28 @@ def _run_pass(gen, xs, ys, lo, hi, batch, out=None):
     workspaces), so that the launch tails and latency-bound layers of one batch run under the next one's."""
     nb = (hi - lo + batch - 1) // batch
     lanes = 1 if (_NESTED[0] or not xs.is_cuda) else min(PASS_LANES[0], nb)
+    if not xs.is_cuda:                           # the CPU rehearsal of the sharding logic (oracle generators)
+        res = [gen(xs[j:min(j + batch, hi)], ys[j:min(j + batch, hi)] if ys is not None else None) for j in range(lo, hi, batch)]
+        return res[0] if len(res) == 1 else torch.cat(res, dim=0)
+    # every batch writes its slices of the pass's volume itself: no concatenation pass behind the generator calls
+    full = torch.empty((hi - lo, gen.high, gen.high), dtype=torch.float32, device=xs.device)
     if lanes <= 1:
-        res = []
         for j in range(lo, hi, batch):
             k = min(j + batch, hi)
-            res.append(gen(xs[j:k], ys[j:k] if ys is not None else None))
-        return res[0] if len(res) == 1 else torch.cat(res, dim=0)
+            gen(xs[j:k], ys[j:k] if ys is not None else None, out=full[j - lo:k - lo])
+        return full
     gens = [gen] + gen.clones(lanes - 1)
     cur = torch.cuda.current_stream()
     streams = [_lane_stream(i) for i in range(lanes)]
     for st in streams:
         st.wait_stream(cur)
-    res = []
     for bi, j in enumerate(range(lo, hi, batch)):
         k = min(j + batch, hi)
         with torch.cuda.stream(streams[bi % lanes]):
-            res.append(gens[bi % lanes](xs[j:k], ys[j:k] if ys is not None else None))
+            gens[bi % lanes](xs[j:k], ys[j:k] if ys is not None else None, out=full[j - lo:k - lo])
     for st in streams:
         cur.wait_stream(st)
-    for r in res:
-        r.record_stream(cur)
-    return torch.cat(res, dim=0)
+    return full
 
 
 # ----------------------------------------------------------------------------
@@ -210,15 +212,22 @@ def _start_gather(comm, local, total):
     return _Now(comm.all_gather_slabs(local, total))
 
 
+def _scaled_velocities(low, up_res, vel_scale, backend):
+    """the three velocity channels of the low-res array times the upres factor (4x.py:278), then vy, vz times the velocity
+    scale (4x.py:283 indexes the 3-channel array with 1:3) -- one marshalling kernel on the call's own stream instead of a
+    slice, a multiply and an in-place multiply of the tensor library"""
+    s2 = None if vel_scale == 1.0 else [1.0, vel_scale, vel_scale]
+    return backend.channel_gather(low, None, [1, 2, 3], [float(up_res)] * 3, s2)
+
+
 def _pass1_4x(gen1, low, up_res, batch, comm, backend, vel_scale, a2a=False):
     """pass 1 of one volume: upsamplingMode 2 -- zoom z, slices along z (4x.py:1103,1126-1133); the
     hand-over of the slabs to pass 2 is started, not awaited"""
     nch = low.shape[3]
     s = low.shape[0] * up_res
     low1 = low
-    if nch > 1 and vel_scale != 1.0:
-        low1 = low.clone()
-        low1[..., 1:4] *= vel_scale                                  # 4x.py:283, first run: vx,vy,vz
+    if nch > 1 and vel_scale != 1.0:                                 # 4x.py:283, first run: vx,vy,vz
+        low1 = backend.channel_gather(low, None, list(range(nch)), [1.0] + [vel_scale] * 3 + [1.0] * (nch - 4))
     xs = backend.axis_zoom_linear(low1, 0, up_res)                   # [s, sim, sim, C]
     lo, hi = slice_range(s, comm)
     out1 = _run_pass(gen1, xs, None, lo, hi, batch)                  # [hi-lo, s, s] = (z, y, x)
@@ -234,14 +243,12 @@ def _pass2_4x(gen2, low, hand, up_res, batch, comm, backend, vel_scale):
     lo, hi = slice_range(s, comm)
     ys, v1 = _finish_hand_over(hand, backend)                        # [hi-lo][z][y]: this rank's x planes of pass 1
     if nch > 1:
-        vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
-        if vel_scale != 1.0:
-            vel[..., 1:3] *= vel_scale                               # 4x.py:283 on the 3-channel array: vy,vz only
+        vel = _scaled_velocities(low, up_res, vel_scale, backend)
         for ax in range(3):                                          # 4x.py:1095
             vel = backend.axis_zoom_linear(vel, ax, up_res)
         # transpose(0,3,1,2,4) then the two channel swaps (d,vx,vy,vz) -> (d,vy,vz,vx); only this rank's x range
         velx = backend.volume_transpose(vel[:, :, lo:hi].contiguous(), (2, 0, 1), chan_map=[1, 2, 0])
-        xin = torch.cat([ys.reshape(hi - lo, s, s, 1), velx], dim=3)
+        xin = backend.channel_gather(ys.reshape(hi - lo, s, s, 1), velx, [0, 1, 2, 3])
     else:
         xin = ys.reshape(hi - lo, s, s, 1)
     out2 = _run_pass(gen2, xin, None, 0, hi - lo, batch)             # [x-range][z][y]
@@ -259,12 +266,10 @@ def refine_pass_4x(gen, low, prev, up_res=4, mode=1, batch=8, comm=None, backend
     # mode 1: transpose(0,3,1,2,4) + swaps 2<->3, 3<->1; mode 3: transpose(0,2,1,3,4) + swap 2<->3
     perm, cmap, back = ((2, 0, 1), [0, 2, 3, 1], (1, 2, 0)) if mode == 1 else ((1, 0, 2), [0, 1, 3, 2], (1, 0, 2))
     if nch > 1:
-        vel = (low[..., 1:4] * float(up_res)).contiguous()           # 4x.py:278
-        if vel_scale != 1.0:
-            vel[..., 1:3] *= vel_scale                               # 4x.py:283 on the 3-channel array: vy,vz only
+        vel = _scaled_velocities(low, up_res, vel_scale, backend)
         for ax in range(3):                                          # 4x.py:1095
             vel = backend.axis_zoom_linear(vel, ax, up_res)
-        xin = backend.volume_transpose(torch.cat([prev.reshape(s, s, s, 1), vel], dim=3), perm, chan_map=cmap)
+        xin = backend.volume_transpose(backend.channel_gather(prev.reshape(s, s, s, 1), vel, [0, 1, 2, 3]), perm, chan_map=cmap)
     else:
         xin = backend.volume_transpose(prev.reshape(s, s, s), perm).reshape(s, s, s, 1)
     out = _run_pass(gen, xin, None, lo, hi, batch)

@@ -242,7 +242,7 @@ def small_pair_ok(cin, cmid, cout, ka, kb, ks=None):
 
 
 def conv2d_small_pair(x, c_off, up_log2, pk_a, pk_b, pk_s, out_hw, bias_a=None, act_a=None, leak_a=0.2, bias_b=None,
-                      act_b=None, leak_b=0.2, want_f32=True, want_g8=False):
+                      act_b=None, leak_b=0.2, want_f32=True, want_g8=False, out=None):
     """y = act_b(conv_b(act_a(conv_a(up(x)) + bias_a)) + conv_s(up(x)) + bias_b): a residual block of <= 8-channel
     convolutions as one launch (mpg_conv2d_small_pair); x: G8 (or fp32 NHWC, converted), pk_*: PackedWeights."""
     lib = _lib.load()
@@ -276,7 +276,12 @@ def conv2d_small_pair(x, c_off, up_log2, pk_a, pk_b, pk_s, out_hw, bias_a=None, 
     d.prec = pk_a.prec
     y = y8 = None
     if want_f32:
-        y = torch.empty((x.n, h, w, pk_b.cout), dtype=torch.float32, device=dev)
+        if out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != x.n * h * w * pk_b.cout or out.device != dev:
+                raise _lib.MpgError("conv2d_small_pair: `out` does not hold a contiguous fp32 [%d,%d,%d,%d]" % (x.n, h, w, pk_b.cout))
+            y = out.view(x.n, h, w, pk_b.cout)
+        else:
+            y = torch.empty((x.n, h, w, pk_b.cout), dtype=torch.float32, device=dev)
         d.y = y.data_ptr()
     if want_g8:
         y8 = G8.empty(x.n, h, w, pk_b.cout, dev, G8_F16)
@@ -531,6 +536,28 @@ def add_adjacent(x, s_off=0, s_cnt=None):
     s_cnt = s - s_off if s_cnt is None else s_cnt
     out = torch.empty((s_cnt, h, w, c + 2), dtype=torch.float32, device=x.device)
     _lib.check(lib.mpg_add_adjacent(_stream(), _ptr(x), s, h * w, c, s_off, s_cnt, _ptr(out)), "mpg_add_adjacent")
+    return out
+
+
+def channel_gather(a, b, cmap, scales=None, scales2=None):
+    """out[..., j] = (cat(a, b)[..., cmap[j]] * scales[j]) * scales2[j] in one pass (mpg_channel_gather): the slice / scale /
+    concat steps of the velocity channels between the passes (multipassGAN-4x.py:278-283, 1113-1119)"""
+    import ctypes
+    lib = _lib.load()
+    a = _dev(a.contiguous(), "a")
+    ca, cb = a.shape[-1], 0
+    if b is not None:
+        b = _dev(b.contiguous(), "b")
+        cb = b.shape[-1]
+        if tuple(b.shape[:-1]) != tuple(a.shape[:-1]):
+            raise _lib.MpgError("channel_gather: %s and %s differ outside the channel axis" % (tuple(a.shape), tuple(b.shape)))
+    n = len(cmap)
+    npix = a.numel() // ca
+    out = torch.empty(tuple(a.shape[:-1]) + (n,), dtype=torch.float32, device=a.device)
+    m = (ctypes.c_int * n)(*[int(c) for c in cmap])
+    sc = (ctypes.c_float * n)(*[float(x) for x in (scales if scales is not None else [1.0] * n)])
+    sc2 = (ctypes.c_float * n)(*[float(x) for x in (scales2 if scales2 is not None else [1.0] * n)])
+    _lib.check(lib.mpg_channel_gather(_stream(), _ptr(a), ca, _ptr(b), cb, npix, m, sc, sc2, n, _ptr(out)), "mpg_channel_gather")
     return out
 
 

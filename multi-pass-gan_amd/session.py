@@ -139,8 +139,10 @@ class Session(object):
         outs = [self.run_device(f, feeds).cpu().numpy() for f in flist]
         return outs[0] if single else outs
 
-    def run_device(self, fetch, feeds):
-        """device tensors in / device tensor out (what the multi-pass pipeline uses)."""
+    def run_device(self, fetch, feeds, out=None):
+        """device tensors in / device tensor out (what the multi-pass pipeline uses).  out: a contiguous fp32 buffer with
+        as many elements as the result; the launch that produces the fetched value writes it there when it is a fused
+        convolution (the slice batches of a pass then land in one volume without a concatenation pass)."""
         _lib.load()
         if not torch.cuda.is_available():
             raise _lib.MpgError("no GPU visible: the multi-pass GAN path has no CPU fallback")
@@ -156,11 +158,24 @@ class Session(object):
         env = {}
         for node, t in feeds.items():
             env[node.id] = t
+        producer = self._producer_of(fetch) if out is not None else None
         for i, (node, fn) in enumerate(plan.steps):
+            env["__out__"] = out if (producer is not None and node.id == producer.id) else None
             env[node.id] = fn(env)
             for nid in plan.free_after[i]:
                 env.pop(nid, None)
-        return self._f32(env, fetch)
+        res = self._f32(env, fetch)
+        if out is not None and res.data_ptr() != out.data_ptr():
+            out.view(-1).copy_(res.reshape(-1))
+            res = out.view(res.shape)
+        return res
+
+    @staticmethod
+    def _producer_of(node):
+        """the node whose buffer `node` aliases: through reshapes"""
+        while node.op == "reshape":
+            node = node.inputs[0]
+        return node
 
     # ------------------------------------------------------------------ tensor formats
     # A fused convolution can emit fp32 NHWC and / or the G8 layout (in either flavour) its consumers
@@ -311,7 +326,8 @@ class Session(object):
                 g8, off = self._g8(env, src0, c_off0, cin_a, ops.G8_F16)
                 res = ops.conv2d_small_pair(g8, off, up0, pk_a, pk_b, pk_s, p2["out_hw"], bias_a=self._bias_for(p1["terms"]),
                                             act_a=p1["act"], leak_a=p1["leak"], bias_b=self._bias_for(p2["terms"]),
-                                            act_b=p2["act"], leak_b=p2["leak"], want_f32=emit2["f32"], want_g8=emit2["g8"])
+                                            act_b=p2["act"], leak_b=p2["leak"], want_f32=emit2["f32"], want_g8=emit2["g8"],
+                                            out=env.get("__out__") if emit2["f32"] else None)
                 res = list(res) if isinstance(res, tuple) else [res]
                 out = {"f32": None, "g8": {}}
                 if emit2["f32"]:
@@ -440,8 +456,11 @@ class Session(object):
             if timed:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
+            dst = env.get("__out__") if emit["f32"] else None
+            if dst is not None:
+                dst = dst.view(seg_objs[0].x.n, out_hw[0], out_hw[1], cout)
             res = ops.conv2d_fused(seg_objs, out_hw, bias=bias, act=act, leak=leak, pixel_norm=pn, pn_eps=pn_eps,
-                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"])
+                                   post_add=pa, want_f32=emit["f32"], want_g8=emit["g8"], out=dst)
             if timed:
                 ev[1].record()
                 self.tap_events.append(ev)

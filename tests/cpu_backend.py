@@ -35,3 +35,12 @@ def add_adjacent(x, s_off=0, s_cnt=None):
 
 def cutoff(v, thr=0.0005, out=None):
     return torch.as_tensor(OM.cutoff(_np(v), thr))
+
+
+def channel_gather(a, b, cmap, scales=None, scales2=None):
+    src = _np(a) if b is None else np.concatenate([_np(a), _np(b)], axis=-1)
+    out = src[..., list(cmap)].astype(np.float32)
+    for sc in (scales, scales2):
+        if sc is not None:
+            out = out * np.asarray(sc, np.float32)
+    return torch.as_tensor(np.ascontiguousarray(out))

@@ -67,3 +67,25 @@ def test_generator_calls_on_four_streams(mpg, prec):
         torch.cuda.synchronize()
         for i, o in enumerate(outs):
             assert torch.equal(o, ref[i % 4]), "call %d differs under concurrency (rep %d)" % (i, rep)
+
+
+def test_four_channel_volumes_on_lanes(mpg):
+    """whole 4-channel volumes (density + velocities: zooms, transposes, the channel marshalling kernel and both generators)
+    as whole-volume lanes against the same volumes one after the other.  Everything between the passes is a kernel of this
+    library on the lane's own stream: no tensor-library elementwise kernel runs beside the convolutions of another lane."""
+    from mpgan_amd import multipass as MP
+    from mpgan_amd.synthetic import synthetic_volume
+    mk = lambda mode, seed: MP.Generator("gen_resnet", dict(tile_low=16, up_res=4, channels=4, upsampling_mode=mode, batch_norm=True),
+                                         None, 2, device=DEV, seed=seed)
+    g1, g2 = mk(2, 5), mk(1, 6)
+    lows = [torch.as_tensor(synthetic_volume(16, 4, 11 + i), device=DEV) for i in range(4)]
+    ref = []
+    for low in lows:
+        ref.append(MP.two_pass_4x(g1, g2, low, 4, batch=8, vel_scale=0.5)[0].clone())
+        torch.cuda.synchronize()
+    lanes = [(g1.clone(), g2.clone()) for _ in range(3)]
+    for rep in range(4):
+        outs = MP.two_pass_4x_batch(g1, g2, lows, 4, batch=8, vel_scale=0.5, lanes=lanes)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            assert torch.equal(o, ref[i]), "volume %d differs on lanes (rep %d)" % (i, rep)

@@ -565,6 +565,24 @@ def test_volume_transpose(gpu_ops, perm):
     assert np.array_equal(y4, v4.transpose(tuple(perm) + (3,))[..., [0, 3, 2, 1]])
 
 
+def test_channel_gather(gpu_ops):
+    """slice / scale / concatenate of channels in one pass, against numpy (multipassGAN-4x.py:278-283, 1113-1119): the two
+    factors are applied one after the other, as the reference multiplies twice"""
+    low = _rng(61).standard_normal((7, 6, 5, 4)).astype(np.float32)
+    vel = gpu_ops.channel_gather(_t(low), None, [1, 2, 3], [4.0] * 3, [1.0, 0.3, 0.3]).cpu().numpy()
+    ref = (low[..., 1:4] * np.float32(4.0)).copy()
+    ref[..., 1:3] *= np.float32(0.3)
+    assert np.array_equal(vel, ref)
+    dens = _rng(67).standard_normal((7, 6, 5, 1)).astype(np.float32)
+    cat = gpu_ops.channel_gather(_t(dens), _t(ref), [0, 1, 2, 3]).cpu().numpy()
+    assert np.array_equal(cat, np.concatenate([dens, ref], axis=3))
+    sw = gpu_ops.channel_gather(_t(low), None, [0, 3, 2, 1, 0], [1, 2, 3, 4, 5]).cpu().numpy()
+    assert np.array_equal(sw, low[..., [0, 3, 2, 1, 0]] * np.asarray([1, 2, 3, 4, 5], np.float32))
+    from mpgan_amd import _lib
+    with pytest.raises(_lib.MpgError):
+        gpu_ops.channel_gather(_t(low), None, [4])
+
+
 def test_add_adjacent_and_cutoff(gpu_ops):
     from oracle import multipass as MP
     x = _rng(53).standard_normal((6, 4, 5, 4)).astype(np.float32)
