@@ -52,6 +52,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef MPG_W0
 #define MPG_W0 1
 #endif
+//   MPG_PIECES_AFTER 0   the LDS-DMA pieces of an fp16 group are issued in front of the group's operand wait (rounds 2-3)
+#ifndef MPG_PIECES_AFTER
+#define MPG_PIECES_AFTER 1
+#endif
 //   MPG_ALT 1       experiment, off: the second half of the waves of an 8-wave block runs a stage's correction steps BEFORE its
 //                   fp16 groups (complementary phases on a SIMD).  As compiled the corrections-first order keeps 265 spilled
 //                   registers at four cout tiles (profiles/r03/kloop_variants.md): not measured on the hardware
@@ -882,18 +886,24 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                 static_for<0, (AH < G16 ? AH : G16)>([&](auto gc) { read_group(gc); });
                 static_for<0, G16>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, j = g / NT, nt = g % NT;
-                    if constexpr (g < HALF) {
-                        if (do_img)
-                            static_for<0, IPG>([&](auto kc) {
-                                constexpr int i = g * IPG + decltype(kc)::value;
-                                if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
+                    // the LDS-DMA pieces of the group: a wave waits 60-185 cycles per piece for the CU's address unit.  Behind
+                    // the group's MFMAs that wait runs under them; in front of the group (rounds 2-3) it delayed the group's
+                    // own operand wait -- with one cout tile (three image pieces per group) the head of a stage was 830 cycles
+                    auto pieces = [&]() {
+                        if constexpr (g < HALF) {
+                            if (do_img)
+                                static_for<0, IPG>([&](auto kc) {
+                                    constexpr int i = g * IPG + decltype(kc)::value;
+                                    if constexpr (i < MAXI) img_piece(img_chunk, std::integral_constant<int, i>{});
+                                });
+                        } else {
+                            static_for<0, WPG>([&](auto kc) {
+                                constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
+                                if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
                             });
-                    } else {
-                        static_for<0, WPG>([&](auto kc) {
-                            constexpr int i = (g - HALF) * WPG + decltype(kc)::value;
-                            if constexpr (i < NI) w_piece(st + D, std::integral_constant<int, i>{});
-                        });
-                    }
+                        }
+                    };
+                    if constexpr (!MPG_PIECES_AFTER) pieces();
                     if constexpr (g + AH < G16) read_group(std::integral_constant<int, g + AH>{});
                     if constexpr (W0_AHEAD && g == G16 - 1) read_w6(std::integral_constant<int, 0>{});
                     lgkm_wait<kx_allowed(g, NT, PT, AH) + (W0_AHEAD && g == G16 - 1 ? 2 : 0)>();   // reads issued behind group g's own
@@ -905,6 +915,7 @@ __global__ __launch_bounds__(Pipe6<NT>::WAVES * 64, 2) void conv_mfma_f6_kernel(
                         constexpr int pt = decltype(pc)::value;
                         acc[pt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[g % (AH + 1)], bh[pt][j], acc[pt][nt], 0, 0, 0);
                     });
+                    if constexpr (MPG_PIECES_AFTER) pieces();
                     // the a_hi block scales and codes (VALU work under the matrix pipe): tile row g - 3 NT behind each group
                     // of the last k-step, whatever is left behind the last group
                     if constexpr (MAKE_HI6) {

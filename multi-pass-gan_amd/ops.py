@@ -231,9 +231,17 @@ def conv2d_fused(segments, out_hw, bias=None, act=None, leak=0.2, pixel_norm=Fal
     return outs[0] if len(outs) == 1 else tuple(outs)
 
 
-def small_pair_ok(cin, cmid, cout, ka, kb, ks=None):
-    """shapes mpg_conv2d_small_pair takes: <= 8 channels everywhere, odd filters up to 7x7, shortcut inside the input tile"""
+PAIR_MAX_CIN = 4
+
+
+def small_pair_ok(cin, cmid, cout, ka, kb, ks=None, planner=False):
+    """shapes mpg_conv2d_small_pair takes: <= 8 channels everywhere, odd filters up to 7x7, shortcut inside the input tile.
+    planner=True: the shapes the launch planner fuses -- only inputs of <= 4 channels: the first convolution is recomputed
+    on the halo of the second (x1.33 at 5x5 on 64x16 tiles), which one launch less pays for at 1 -> 2 -> 8 (26.8 against
+    37.6 us per 8 slices of 256^2) and not at 8 -> 2 -> 1 (50.0 against 37.1 us; tools/probe_small.py)"""
     if not (1 <= cin <= 8 and 1 <= cmid <= 8 and 1 <= cout <= 8):
+        return False
+    if planner and cin > PAIR_MAX_CIN:
         return False
     for k in (ka, kb) + ((ks,) if ks is not None else ()):
         if k[0] % 2 == 0 or k[1] % 2 == 0 or max(k) > 7:

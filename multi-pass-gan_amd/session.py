@@ -313,7 +313,7 @@ class Session(object):
                     continue
             ka, kb = tuple(term_a.conv.inputs[1].shape[:2]), tuple(term_b.conv.inputs[1].shape[:2])
             ks = tuple(term_s.conv.inputs[1].shape[:2]) if term_s is not None else None
-            if not ops.small_pair_ok(cin_a, p1["cout"], p2["cout"], ka, kb, ks):
+            if not ops.small_pair_ok(cin_a, p1["cout"], p2["cout"], ka, kb, ks, planner=True):
                 continue
             emit2 = fn2.emit
 
