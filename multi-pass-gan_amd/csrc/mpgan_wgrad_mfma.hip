@@ -75,6 +75,9 @@ __global__ void amax_init_kernel(float* __restrict__ amax, const float* __restri
 #ifndef MPG_WG_SPREAD
 #define MPG_WG_SPREAD 0
 #endif
+#ifndef MPG_WG_RING        // 0: square 3x3 / 4x4 / 5x5 filters on the one-filter-row kernel too (development A/B)
+#define MPG_WG_RING 1
+#endif
 #if MPG_WG_DIAG
 __device__ unsigned long long g_wg_diag[8];
 #define WG_T() __builtin_readcyclecounter()
@@ -488,6 +491,291 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_mfma_kernel(WgArgs a) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same product with ALL filter rows of a tile in one block ("ring" form; square 3x3, 4x4 and 5x5 filters).
+//
+// The kernel above gives a block ONE filter row: every x row is then staged once per filter row and cout window (10 times
+// for a 5x5 128 -> 128 layer), every dy row once per filter row, 60 KB per chunk of 64 pixels for 3840 cycles of MFMA work
+// -- and the L2 -> LDS copy is what the launch waits for (10 B/clk/CU, profiles/r03/wgrad_variants.md).  Here a block owns a
+// 32-channel ci tile x a cout window x all KH x KW taps over a column chunk of 64 pixels and sweeps a range of output
+// rows: the KH x rows an output row needs stay in an LDS ring of KH + 1 row slots, so ONE new x row and one dy row are
+// copied per output row: 28 KB for 4800 cycles of MFMA work.  The KH * KW * COTW accumulator tiles (50 at 5x5 with a
+// 64-wide window) are dealt to the 8 waves in (ky, kx, cout tile) order, 6 or 7 each; a wave reads the 24-pixel windows
+// of the one or two filter rows its tiles touch.  Which tiles a wave owns is a compile-time property of its number: the
+// k-step body exists once per wave (`switch` on the scalar wave number), registers are statically indexed.
+struct WrArgs {
+    const char* xg;
+    const char* dg;
+    const float* x_amax;
+    const float* d_amax;
+    const char* zeros;
+    float* dw;
+    int n, h, w;
+    int x_cg, d_cg;
+    int cin_total, cout_total;
+    int pt;
+    int chunks;              // column chunks of WR_PX pixels per row
+    int ranges, rows_per_range;
+    int n_ci, n_cow;         // ci tiles of 32, cout windows of 32 * COTW
+    int n_outer;             // n * ranges * chunks
+    float wscale;
+};
+
+constexpr int WR_PX = 64;                      // pixels of a column chunk
+constexpr int WR_XP = WR_PX + 16 + LDS_ROW_PAD, WR_DP = WR_PX + LDS_ROW_PAD;      // units per LDS row of a group
+constexpr int WR_XSLOT = 2 * 4 * WR_XP * 16;   // an x row: 2 planes x 4 groups
+constexpr int wr_pairs(int kh, int kw, int cotw) { return kh * kw * cotw; }
+constexpr int wr_first(int wave, int np) { return wave * np / WG_WAVES; }        // first (ky, kx, cot) pair of a wave
+constexpr int wr_max_pairs(int np) { return (np + WG_WAVES - 1) / WG_WAVES; }
+
+template <int KH, int KW, int COTW, int PREC>
+__global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int NP = wr_pairs(KH, KW, COTW), MAXP = wr_max_pairs(NP), RX = KH + 1;
+    constexpr int GD = COTW * 4;                                   // channel groups of the dy image
+    constexpr int DBUF = 2 * GD * WR_DP * 16;                      // one dy buffer (both planes laid out; PREC 1 reads plane 0)
+    constexpr int XUNITS = 2 * 4 * WR_XP, DUNITS = 2 * GD * WR_DP;
+    constexpr int XU = (XUNITS + WG_THREADS - 1) / WG_THREADS, DU = (DUNITS + WG_THREADS - 1) / WG_THREADS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    // block -> (image, row range, column chunk) x (ci tile, cout window); the combinations of one outer index run next to
+    // each other on one XCD (they share the x rows / the dy rows through its L2)
+    const int ncombo = a.n_ci * a.n_cow;
+    const int xcd = blockIdx.x % 8, t = blockIdx.x / 8;
+    const int combo = t % ncombo, outer = (t / ncombo) * 8 + xcd;
+    if (outer >= a.n_outer) return;
+    const int cit = combo % a.n_ci, cow = combo / a.n_ci;
+    const int chunk = outer % a.chunks, rng = (outer / a.chunks) % a.ranges, b = outer / (a.chunks * a.ranges);
+    const int x0 = chunk * WR_PX;
+    const int row0 = rng * a.rows_per_range, row1 = min(a.h, row0 + a.rows_per_range);
+    if (row0 >= row1) return;
+    const int plane_px = a.h * a.w;
+    char* xs = lds;
+    char* dsm = lds + RX * WR_XSLOT;
+
+    // copy plan: per unit its offset (16-byte units) from pixel x0 of plane 0 of group 0 of the row, and its pixel offset
+    constexpr int NOPX = 1 << 28, SKIP = -(1 << 28);
+    int xg[XU], xpo[XU], dg[DU], dpo[DU];
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+        const int u = tid + i * WG_THREADS;
+        const int rr = u / WR_XP, off = u % WR_XP;
+        const int pln = rr / 4, g = cit * 4 + rr % 4;
+        xg[i] = (g * 2 + pln) * plane_px + off - 8;
+        xpo[i] = (u >= XUNITS || off >= WR_PX + 16 || (PREC != 3 && pln == 1)) ? SKIP : (g < a.x_cg ? off - 8 : NOPX);
+    }
+#pragma unroll
+    for (int i = 0; i < DU; ++i) {
+        const int u = tid + i * WG_THREADS;
+        const int rr = u / WR_DP, off = u % WR_DP;
+        const int pln = rr / GD, g = cow * GD + rr % GD;
+        dg[i] = (g * 2 + pln) * plane_px + off;
+        dpo[i] = (u >= DUNITS || off >= WR_PX || (PREC != 3 && pln == 1)) ? SKIP : (g < a.d_cg ? off : NOPX);
+    }
+    const char* ximg = a.xg + ((size_t)b * a.x_cg * 2) * plane_px * 16;
+    const char* dimg = a.dg + ((size_t)b * a.d_cg * 2) * plane_px * 16;
+    auto copy_x_row = [&](int iy, int slot) {          // image row iy (zeros outside the image) -> ring slot
+        const bool ok = iy >= 0 && iy < a.h;
+        const char* row = ximg + ((size_t)(ok ? iy : 0) * a.w + x0) * 16;
+#pragma unroll
+        for (int i = 0; i < XU; ++i)
+            if (xpo[i] != SKIP) {
+                const int px = x0 + xpo[i];
+                const char* src = (ok && px >= 0 && px < a.w) ? row + (ptrdiff_t)xg[i] * 16 : a.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + slot * WR_XSLOT + (i * WG_WAVES + wave) * 1024),
+                                                 16, 0, 0);
+            }
+    };
+    auto copy_d_row = [&](int oy, int buf) {
+        const char* row = dimg + ((size_t)oy * a.w + x0) * 16;
+#pragma unroll
+        for (int i = 0; i < DU; ++i)
+            if (dpo[i] != SKIP) {
+                const char* src = (x0 + dpo[i] < a.w) ? row + (ptrdiff_t)dg[i] * 16 : a.zeros;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dsm + buf * DBUF + (i * WG_WAVES + wave) * 1024),
+                                                 16, 0, 0);
+            }
+    };
+
+    f32x16 acc[MAXP];
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[s][v] = 0.f;
+
+    // ring: x row iy = oy + ky - pt lives in slot (oy + ky) % RX
+    int base = row0 % RX;                              // slot of filter row 0 of the current output row
+#pragma unroll
+    for (int ky = 0; ky < KH; ++ky) copy_x_row(row0 + ky - a.pt, (base + ky) % RX);
+    copy_d_row(row0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int ksteps = (min(WR_PX, a.w - x0) + 15) / 16;
+    // lane part of the transposed-read addresses (see wgrad_mfma_kernel): 16 lanes own 16 channels = two groups
+    const int sub = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+    const unsigned xlane = lds_off(xs) + ((sub * 2 + (tp >> 1)) * WR_XP + 8 * hh + tq) * 16 + (tp & 1) * 8;
+    const unsigned dlane = lds_off(dsm) + ((sub * 2 + (tp >> 1)) * WR_DP + 8 * hh + tq) * 16 + (tp & 1) * 8;
+    constexpr int XPLANE = 4 * WR_XP * 16, DPLANE = GD * WR_DP * 16, DTILE = 4 * WR_DP * 16;
+
+    // one 16-pixel k-step of wave W: compile-time list of its (ky, kx, cot) pairs
+    auto kstep = [&](auto wc, int j, unsigned dbase) {
+        constexpr int W = decltype(wc)::value;
+        constexpr int P0 = wr_first(W, NP), P1 = wr_first(W + 1, NP), CNT = P1 - P0;
+        constexpr int KY0 = P0 / (KW * COTW), KY1 = (P1 - 1) / (KW * COTW), NKY = KY1 - KY0 + 1;
+        static_assert(CNT >= 1 && CNT <= MAXP && NKY <= 2, "tile split");
+        // the lo windows arrive in the registers of the hi ones, behind the two products that read those: at 7 tiles per wave
+        // both sets of windows at once do not fit beside the accumulators
+        u32x2 wh[NKY][6], bhq[COTW][2], blq[COTW][2];
+        unsigned xa[NKY];
+#pragma unroll
+        for (int k = 0; k < NKY; ++k) {
+            int slot = base + KY0 + k;
+            slot = slot >= RX ? slot - RX : slot;
+            xa[k] = xlane + slot * WR_XSLOT + j * 256;
+        }
+        const unsigned da = dlane + dbase + j * 256;
+#pragma unroll
+        for (int k = 0; k < NKY; ++k)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) tr_read_at(wh[k][m], xa[k], m);
+#pragma unroll
+        for (int c = 0; c < COTW; ++c) {
+            lds_read_tr<0>(bhq[c][0], da + c * DTILE);
+            lds_read_tr<64>(bhq[c][1], da + c * DTILE);
+        }
+        if (PREC == 3) {
+#pragma unroll
+            for (int c = 0; c < COTW; ++c) {
+                lds_read_tr<0>(blq[c][0], da + DPLANE + c * DTILE);
+                lds_read_tr<64>(blq[c][1], da + DPLANE + c * DTILE);
+            }
+        }
+        auto frag_of = [](const u32x2 (&q)[2]) {
+            u32x4 f;
+            f[0] = q[0][0]; f[1] = q[0][1]; f[2] = q[1][0]; f[3] = q[1][1];
+            return __builtin_bit_cast(half8, f);
+        };
+        // pixels [8 + s, 16 + s) of a window, s = kx - pl
+        auto shifted = [&](const u32x2 (&wq)[6], auto kxc) {
+            constexpr int kx = decltype(kxc)::value, s = kx - (KW - 1) / 2;
+            u32x4 f;
+            if constexpr ((s & 1) == 0) {
+                constexpr int q = (8 + s) / 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = wq[(q + i) / 2][(q + i) % 2];
+            } else {
+                constexpr int q = (7 + s) / 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    f[i] = __builtin_amdgcn_alignbit(wq[(q + i + 1) / 2][(q + i + 1) % 2], wq[(q + i) / 2][(q + i) % 2], 16);
+            }
+            return __builtin_bit_cast(half8, f);
+        };
+        constexpr int NLATE = PREC == 3 ? 2 * COTW : 0;                // reads issued behind the hi operands
+        lgkm_wait<NLATE>();
+#pragma unroll
+        for (int k = 0; k < NKY; ++k)
+#pragma unroll
+            for (int m = 0; m < 6; ++m) tie(wh[k][m]);
+        half8 bh[COTW], bl[COTW];
+#pragma unroll
+        for (int c = 0; c < COTW; ++c) { tie(bhq[c][0]); tie(bhq[c][1]); bh[c] = frag_of(bhq[c]); }
+        // product-major: consecutive MFMAs go to different accumulators
+        static_for_wg<0, CNT>([&](auto sc) {
+            constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+            acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bh[c], acc[decltype(sc)::value], 0, 0, 0);
+        });
+        if (PREC == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            lgkm_wait<0>();
+#pragma unroll
+            for (int c = 0; c < COTW; ++c) { tie(blq[c][0]); tie(blq[c][1]); bl[c] = frag_of(blq[c]); }
+            static_for_wg<0, CNT>([&](auto sc) {
+                constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+                acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bl[c], acc[decltype(sc)::value], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NKY; ++k)
+#pragma unroll
+                for (int m = 0; m < 6; ++m) tr_read_at(wh[k][m], xa[k] + XPLANE, m);
+            lgkm_wait<0>();
+#pragma unroll
+            for (int k = 0; k < NKY; ++k)
+#pragma unroll
+                for (int m = 0; m < 6; ++m) tie(wh[k][m]);
+            static_for_wg<0, CNT>([&](auto sc) {
+                constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+                acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bh[c], acc[decltype(sc)::value], 0, 0, 0);
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int oy = row0; oy < row1; ++oy) {
+        const int buf = (oy - row0) & 1;
+        // the x row the NEXT output row adds and its dy row, whole at the head of the step (see MPG_WG_SPREAD above): the
+        // slot it goes to held filter row 0 of the previous output row
+        if (oy + 1 < row1) {
+            int slot = base + KH;
+            slot = slot >= RX ? slot - RX : slot;
+            copy_x_row(oy + KH - a.pt, slot);
+            copy_d_row(oy + 1, buf ^ 1);
+        }
+        const unsigned dbase = buf * DBUF;
+        for (int j = 0; j < ksteps; ++j) {
+            switch (wave) {
+                case 0: kstep(std::integral_constant<int, 0>{}, j, dbase); break;
+                case 1: kstep(std::integral_constant<int, 1>{}, j, dbase); break;
+                case 2: kstep(std::integral_constant<int, 2>{}, j, dbase); break;
+                case 3: kstep(std::integral_constant<int, 3>{}, j, dbase); break;
+                case 4: kstep(std::integral_constant<int, 4>{}, j, dbase); break;
+                case 5: kstep(std::integral_constant<int, 5>{}, j, dbase); break;
+                case 6: kstep(std::integral_constant<int, 6>{}, j, dbase); break;
+                default: kstep(std::integral_constant<int, 7>{}, j, dbase); break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        base = base + 1 >= RX ? 0 : base + 1;
+    }
+
+    // epilogue: D row = (v&3) + 8*(v>>2) + 4*(lane>>5) is the input channel, column lane&31 the output channel
+    const float unscale = a.wscale / ((a.x_amax ? pow2_scale(*a.x_amax) : 1.f) * (a.d_amax ? pow2_scale(*a.d_amax) : 1.f));
+    const int p0 = wave * NP / WG_WAVES, p1 = (wave + 1) * NP / WG_WAVES;
+#pragma unroll
+    for (int s = 0; s < MAXP; ++s) {
+        const int p = p0 + s;
+        if (p >= p1) break;
+        const int ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+        const int co = (cow * COTW + c) * 32 + r;
+        if (co >= a.cout_total) continue;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int ci = cit * 32 + (v & 3) + 8 * (v >> 2) + 4 * hh;
+            const float val = acc[s][v];
+            if (ci < a.cin_total && val != 0.f)
+                atomicAdd(a.dw + ((size_t)(ky * KW + kx) * a.cin_total + ci) * a.cout_total + co, val * unscale);
+        }
+    }
+}
+
+template <int KH, int KW, int COTW, int PREC>
+hipError_t launch_ring(hipStream_t s, const WrArgs& a, int blocks) {
+    auto kern = wgrad_ring_kernel<KH, KW, COTW, PREC>;
+    static int lds_limit[64] = {0};
+    constexpr size_t lds = (size_t)(KH + 1) * WR_XSLOT + 2 * (size_t)(2 * COTW * 4 * WR_DP * 16);
+    static_assert(lds <= 160 * 1024, "ring kernel LDS plan");
+    hipError_t e = mpg::ensure_dyn_lds((const void*)kern, 160 * 1024, lds_limit);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(WG_THREADS), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int KW, int COTW, int PREC>
 hipError_t launch(hipStream_t s, const WgArgs& a, int blocks, size_t lds_bytes, int windows) {
     auto kern = wgrad_mfma_kernel<KW, COTW, PREC>;
@@ -508,6 +796,46 @@ int wgrad_launches(hipStream_t s, const char* xg, const char* dg, const float* x
     MPG_REQUIRE((size_t)((cin > cout ? cin : cout) + 7) / 8 * 2 * h * w < (1u << 30), "mpg_conv2d_wgrad: image too large");
     hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad: memset");
+    // all filter rows of a tile in one block, x rows in an LDS ring (wgrad_ring_kernel): 1.1 .. 3x faster than the one-filter-row
+    // kernel on every 3x3 / 4x4 / 5x5 shape of the training steps (tools/probe_wgrad_shapes.py, profiles/r03/wgrad_variants.md)
+    // except the widest 5x5 layers on large tiles -- 32-wide cout windows there (see below), steps too short for their
+    // barrier: 3.07 against 2.55 ms at 128 -> 128 on 16 tiles of 256^2 (0.25 against 0.30 ms on tiles of 64^2)
+    const bool wide5 = kh == 5 && cout > 32 && cin > 32 && (size_t)n * h * w > (size_t)16 * 128 * 128;
+    if (MPG_WG_RING && kh == kw && (kh == 3 || kh == 4 || kh == 5) && !wide5) {
+        const int nco = (cout + 31) / 32;
+        // cout tiles per window: as many as leave <= 6 accumulator tiles per wave (5x5 with a 64-wide window is 7 on two of
+        // the waves and compiled to 28 spilled registers: 32-wide windows there, 4 tiles on one wave, 3 on the others)
+        const int cotw = kh == 3 ? (nco >= 3 ? 4 : nco) : (kh == 4 && nco >= 2 ? 2 : 1);
+        WrArgs a;
+        a.xg = xg; a.dg = dg; a.x_amax = x_amax; a.d_amax = d_amax; a.zeros = zeros; a.dw = dw;
+        a.n = n; a.h = h; a.w = w;
+        a.x_cg = (cin + 7) / 8; a.d_cg = (cout + 7) / 8;
+        a.cin_total = cin; a.cout_total = cout;
+        a.pt = (kh - 1) / 2;
+        a.wscale = wscale;
+        a.chunks = (w + WR_PX - 1) / WR_PX;
+        a.n_ci = (cin + 31) / 32;
+        a.n_cow = (cout + 32 * cotw - 1) / (32 * cotw);
+        // row ranges: a block pays for KH rows before its first output row, so ranges are as long as still leaves ~1024
+        // blocks (4 per CU) to balance the chip
+        const int per_range = n * a.chunks * a.n_ci * a.n_cow;
+        int rs = (1024 + per_range - 1) / per_range;
+        const int max_rs = h / 8 > 1 ? h / 8 : 1;
+        if (rs > max_rs) rs = max_rs;
+        if (rs < 1) rs = 1;
+        a.rows_per_range = (h + rs - 1) / rs;
+        a.ranges = (h + a.rows_per_range - 1) / a.rows_per_range;
+        a.n_outer = n * a.ranges * a.chunks;
+        const int blocks = ((a.n_outer + 7) / 8) * 8 * a.n_ci * a.n_cow;
+        hipError_t le = hipErrorInvalidValue;
+#define MPG_WR(K, C)                                                                      \
+    if (kh == K && cotw == C)                                                             \
+        le = prec == MPG_PREC_F16X3 ? launch_ring<K, K, C, 3>(s, a, blocks) : launch_ring<K, K, C, 1>(s, a, blocks)
+        MPG_WR(3, 1); MPG_WR(3, 2); MPG_WR(3, 4); MPG_WR(4, 1); MPG_WR(4, 2); MPG_WR(5, 1);
+#undef MPG_WR
+        if (le != hipSuccess) return mpg::hip_check(le, "wgrad_ring_kernel");
+        MPG_LAUNCH_CHECK("mpg_conv2d_wgrad (ring)");
+    }
     // a wave keeps KW * COTW accumulator tiles of 16 registers, 6 at most beside its fragments (256 registers per wave at two
     // waves per SIMD; 8 tiles compiled to 3 spilled registers), so a 4- or 5-wide filter row takes 64 output channels per
     // window (x is then staged twice, from L2)
