@@ -554,24 +554,36 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
     char* xs = lds;
     char* dsm = lds + RX * WR_XSLOT;
 
-    // copy plan: per unit its offset (16-byte units) from pixel x0 of plane 0 of group 0 of the row, and its pixel offset
-    constexpr int NOPX = 1 << 28, SKIP = -(1 << 28);
-    int xg[XU], xpo[XU], dg[DU], dpo[DU];
+    // copy plan: per 16-byte unit of this thread its offset (in units) from pixel x0 of plane 0 of group 0 of the row, or
+    // NOCOPY.  What a unit holds for the whole launch is decided here: pad units and the unused lo plane are never touched;
+    // channel groups the tensor does not have (8 -> 128: three of the four groups of the ci tile) and pixels outside the
+    // image's columns (the block owns ONE column chunk) are zeroed once, in every ring slot / both dy buffers.
+    constexpr int NOCOPY = -(1 << 30);
+    int xg[XU], dg[DU];
 #pragma unroll
     for (int i = 0; i < XU; ++i) {
         const int u = tid + i * WG_THREADS;
         const int rr = u / WR_XP, off = u % WR_XP;
         const int pln = rr / 4, g = cit * 4 + rr % 4;
-        xg[i] = (g * 2 + pln) * plane_px + off - 8;
-        xpo[i] = (u >= XUNITS || off >= WR_PX + 16 || (PREC != 3 && pln == 1)) ? SKIP : (g < a.x_cg ? off - 8 : NOPX);
+        const int px = x0 + off - 8;
+        const bool unused = u >= XUNITS || off >= WR_PX + 16 || (PREC != 3 && pln == 1);
+        const bool zero = !unused && (g >= a.x_cg || px < 0 || px >= a.w);
+        xg[i] = (unused || zero) ? NOCOPY : (g * 2 + pln) * plane_px + off - 8;
+        if (zero)
+            for (int slot = 0; slot < RX; ++slot)
+                *reinterpret_cast<u32x4*>(xs + slot * WR_XSLOT + u * 16) = u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < DU; ++i) {
         const int u = tid + i * WG_THREADS;
         const int rr = u / WR_DP, off = u % WR_DP;
         const int pln = rr / GD, g = cow * GD + rr % GD;
-        dg[i] = (g * 2 + pln) * plane_px + off;
-        dpo[i] = (u >= DUNITS || off >= WR_PX || (PREC != 3 && pln == 1)) ? SKIP : (g < a.d_cg ? off : NOPX);
+        const bool unused = u >= DUNITS || off >= WR_PX || (PREC != 3 && pln == 1);
+        const bool zero = !unused && (g >= a.d_cg || x0 + off >= a.w);
+        dg[i] = (unused || zero) ? NOCOPY : (g * 2 + pln) * plane_px + off;
+        if (zero)
+            for (int bufi = 0; bufi < 2; ++bufi)
+                *reinterpret_cast<u32x4*>(dsm + bufi * DBUF + u * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     const char* ximg = a.xg + ((size_t)b * a.x_cg * 2) * plane_px * 16;
     const char* dimg = a.dg + ((size_t)b * a.d_cg * 2) * plane_px * 16;
@@ -580,9 +592,8 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
         const char* row = ximg + ((size_t)(ok ? iy : 0) * a.w + x0) * 16;
 #pragma unroll
         for (int i = 0; i < XU; ++i)
-            if (xpo[i] != SKIP) {
-                const int px = x0 + xpo[i];
-                const char* src = (ok && px >= 0 && px < a.w) ? row + (ptrdiff_t)xg[i] * 16 : a.zeros;
+            if (xg[i] != NOCOPY) {
+                const char* src = ok ? row + (ptrdiff_t)xg[i] * 16 : a.zeros;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(xs + slot * WR_XSLOT + (i * WG_WAVES + wave) * 1024),
                                                  16, 0, 0);
@@ -592,12 +603,10 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
         const char* row = dimg + ((size_t)oy * a.w + x0) * 16;
 #pragma unroll
         for (int i = 0; i < DU; ++i)
-            if (dpo[i] != SKIP) {
-                const char* src = (x0 + dpo[i] < a.w) ? row + (ptrdiff_t)dg[i] * 16 : a.zeros;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+            if (dg[i] != NOCOPY)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(row + (ptrdiff_t)dg[i] * 16),
                                                  (__attribute__((address_space(3))) void*)(dsm + buf * DBUF + (i * WG_WAVES + wave) * 1024),
                                                  16, 0, 0);
-            }
     };
 
     f32x16 acc[MAXP];
@@ -621,39 +630,49 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
     const unsigned dlane = lds_off(dsm) + ((sub * 2 + (tp >> 1)) * WR_DP + 8 * hh + tq) * 16 + (tp & 1) * 8;
     constexpr int XPLANE = 4 * WR_XP * 16, DPLANE = GD * WR_DP * 16, DTILE = 4 * WR_DP * 16;
 
-    // one 16-pixel k-step of wave W: compile-time list of its (ky, kx, cot) pairs
-    auto kstep = [&](auto wc, int j, unsigned dbase) {
+    // the k-steps of one output row for wave W: compile-time list of its (ky, kx, cot) pairs.  LDS reads run ahead of their
+    // MFMAs: in issue order hi windows, hi dy, lo dy, lo windows; the hi windows of the NEXT k-step go out behind the second
+    // product (the last reader of this k-step's), the rest behind the third.  The last k-step issues its look-ahead reads at
+    // its own addresses: the waits count them.
+    auto row_body = [&](auto wc, unsigned dbase) {
         constexpr int W = decltype(wc)::value;
         constexpr int P0 = wr_first(W, NP), P1 = wr_first(W + 1, NP), CNT = P1 - P0;
         constexpr int KY0 = P0 / (KW * COTW), KY1 = (P1 - 1) / (KW * COTW), NKY = KY1 - KY0 + 1;
         static_assert(CNT >= 1 && CNT <= MAXP && NKY <= 2, "tile split");
-        // the lo windows arrive in the registers of the hi ones, behind the two products that read those: at 7 tiles per wave
-        // both sets of windows at once do not fit beside the accumulators
-        u32x2 wh[NKY][6], bhq[COTW][2], blq[COTW][2];
-        unsigned xa[NKY];
+        u32x2 wh[NKY][6], wl[NKY][6], bhq[COTW][2], blq[COTW][2];
+        unsigned xa0[NKY];
 #pragma unroll
         for (int k = 0; k < NKY; ++k) {
             int slot = base + KY0 + k;
             slot = slot >= RX ? slot - RX : slot;
-            xa[k] = xlane + slot * WR_XSLOT + j * 256;
+            xa0[k] = xlane + slot * WR_XSLOT;
         }
-        const unsigned da = dlane + dbase + j * 256;
+        const unsigned da0 = dlane + dbase;
+        auto read_wh = [&](int j) {
 #pragma unroll
-        for (int k = 0; k < NKY; ++k)
+            for (int k = 0; k < NKY; ++k)
 #pragma unroll
-            for (int m = 0; m < 6; ++m) tr_read_at(wh[k][m], xa[k], m);
-#pragma unroll
-        for (int c = 0; c < COTW; ++c) {
-            lds_read_tr<0>(bhq[c][0], da + c * DTILE);
-            lds_read_tr<64>(bhq[c][1], da + c * DTILE);
-        }
-        if (PREC == 3) {
+                for (int m = 0; m < 6; ++m) tr_read_at(wh[k][m], xa0[k] + j * 256, m);
+        };
+        auto read_rest = [&](int j) {
+            const unsigned da = da0 + j * 256;
 #pragma unroll
             for (int c = 0; c < COTW; ++c) {
-                lds_read_tr<0>(blq[c][0], da + DPLANE + c * DTILE);
-                lds_read_tr<64>(blq[c][1], da + DPLANE + c * DTILE);
+                lds_read_tr<0>(bhq[c][0], da + c * DTILE);
+                lds_read_tr<64>(bhq[c][1], da + c * DTILE);
             }
-        }
+            if (PREC == 3) {
+#pragma unroll
+                for (int c = 0; c < COTW; ++c) {
+                    lds_read_tr<0>(blq[c][0], da + DPLANE + c * DTILE);
+                    lds_read_tr<64>(blq[c][1], da + DPLANE + c * DTILE);
+                }
+#pragma unroll
+                for (int k = 0; k < NKY; ++k)
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) tr_read_at(wl[k][m], xa0[k] + XPLANE + j * 256, m);
+            }
+        };
         auto frag_of = [](const u32x2 (&q)[2]) {
             u32x4 f;
             f[0] = q[0][0]; f[1] = q[0][1]; f[2] = q[1][0]; f[3] = q[1][1];
@@ -675,45 +694,53 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
             }
             return __builtin_bit_cast(half8, f);
         };
-        constexpr int NLATE = PREC == 3 ? 2 * COTW : 0;                // reads issued behind the hi operands
-        lgkm_wait<NLATE>();
-#pragma unroll
-        for (int k = 0; k < NKY; ++k)
-#pragma unroll
-            for (int m = 0; m < 6; ++m) tie(wh[k][m]);
-        half8 bh[COTW], bl[COTW];
-#pragma unroll
-        for (int c = 0; c < COTW; ++c) { tie(bhq[c][0]); tie(bhq[c][1]); bh[c] = frag_of(bhq[c]); }
-        // product-major: consecutive MFMAs go to different accumulators
-        static_for_wg<0, CNT>([&](auto sc) {
-            constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
-            acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bh[c], acc[decltype(sc)::value], 0, 0, 0);
-        });
-        if (PREC == 3) {
-            __builtin_amdgcn_sched_barrier(0);
-            lgkm_wait<0>();
-#pragma unroll
-            for (int c = 0; c < COTW; ++c) { tie(blq[c][0]); tie(blq[c][1]); bl[c] = frag_of(blq[c]); }
-            static_for_wg<0, CNT>([&](auto sc) {
-                constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
-                acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bl[c], acc[decltype(sc)::value], 0, 0, 0);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < NKY; ++k)
-#pragma unroll
-                for (int m = 0; m < 6; ++m) tr_read_at(wh[k][m], xa[k] + XPLANE, m);
-            lgkm_wait<0>();
+        constexpr int NW = 6 * NKY, NB = 2 * COTW;
+        read_wh(0);
+        read_rest(0);
+        for (int j = 0; j < ksteps; ++j) {
+            const int jn = j + 1 < ksteps ? j + 1 : j;
+            // in flight, oldest first: wh, bh [, bl, wl]
+            lgkm_wait<(PREC == 3 ? NB + NW : 0)>();
 #pragma unroll
             for (int k = 0; k < NKY; ++k)
 #pragma unroll
                 for (int m = 0; m < 6; ++m) tie(wh[k][m]);
+            half8 bh[COTW], bl[COTW];
+#pragma unroll
+            for (int c = 0; c < COTW; ++c) { tie(bhq[c][0]); tie(bhq[c][1]); bh[c] = frag_of(bhq[c]); }
+            // product-major: consecutive MFMAs go to different accumulators
             static_for_wg<0, CNT>([&](auto sc) {
                 constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
                 acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bh[c], acc[decltype(sc)::value], 0, 0, 0);
             });
+            __builtin_amdgcn_sched_barrier(0);
+            if (PREC == 3) {
+                lgkm_wait<NW>();
+#pragma unroll
+                for (int c = 0; c < COTW; ++c) { tie(blq[c][0]); tie(blq[c][1]); bl[c] = frag_of(blq[c]); }
+                static_for_wg<0, CNT>([&](auto sc) {
+                    constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+                    acc[decltype(sc)::value] = WG_MFMA(shifted(wh[ky - KY0], std::integral_constant<int, kx>{}), bl[c], acc[decltype(sc)::value], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                read_wh(jn);                        // behind the last reader of this k-step's hi windows
+                lgkm_wait<NW>();                    // ... the lo windows are there
+#pragma unroll
+                for (int k = 0; k < NKY; ++k)
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) tie(wl[k][m]);
+                static_for_wg<0, CNT>([&](auto sc) {
+                    constexpr int p = P0 + decltype(sc)::value, ky = p / (KW * COTW), kx = (p / COTW) % KW, c = p % COTW;
+                    acc[decltype(sc)::value] = WG_MFMA(shifted(wl[ky - KY0], std::integral_constant<int, kx>{}), bh[c], acc[decltype(sc)::value], 0, 0, 0);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                read_rest(jn);
+            } else {
+                read_wh(jn);
+                read_rest(jn);
+            }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        lgkm_wait<0>();                             // the look-ahead reads of the last k-step
     };
 
     for (int oy = row0; oy < row1; ++oy) {
@@ -727,17 +754,15 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad_ring_kernel(WrArgs a) {
             copy_d_row(oy + 1, buf ^ 1);
         }
         const unsigned dbase = buf * DBUF;
-        for (int j = 0; j < ksteps; ++j) {
-            switch (wave) {
-                case 0: kstep(std::integral_constant<int, 0>{}, j, dbase); break;
-                case 1: kstep(std::integral_constant<int, 1>{}, j, dbase); break;
-                case 2: kstep(std::integral_constant<int, 2>{}, j, dbase); break;
-                case 3: kstep(std::integral_constant<int, 3>{}, j, dbase); break;
-                case 4: kstep(std::integral_constant<int, 4>{}, j, dbase); break;
-                case 5: kstep(std::integral_constant<int, 5>{}, j, dbase); break;
-                case 6: kstep(std::integral_constant<int, 6>{}, j, dbase); break;
-                default: kstep(std::integral_constant<int, 7>{}, j, dbase); break;
-            }
+        switch (wave) {
+            case 0: row_body(std::integral_constant<int, 0>{}, dbase); break;
+            case 1: row_body(std::integral_constant<int, 1>{}, dbase); break;
+            case 2: row_body(std::integral_constant<int, 2>{}, dbase); break;
+            case 3: row_body(std::integral_constant<int, 3>{}, dbase); break;
+            case 4: row_body(std::integral_constant<int, 4>{}, dbase); break;
+            case 5: row_body(std::integral_constant<int, 5>{}, dbase); break;
+            case 6: row_body(std::integral_constant<int, 6>{}, dbase); break;
+            default: row_body(std::integral_constant<int, 7>{}, dbase); break;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -796,16 +821,15 @@ int wgrad_launches(hipStream_t s, const char* xg, const char* dg, const float* x
     MPG_REQUIRE((size_t)((cin > cout ? cin : cout) + 7) / 8 * 2 * h * w < (1u << 30), "mpg_conv2d_wgrad: image too large");
     hipError_t e = mpg::zero_async(dw, (size_t)kh * kw * cin * cout * sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_conv2d_wgrad: memset");
-    // all filter rows of a tile in one block, x rows in an LDS ring (wgrad_ring_kernel): 1.1 .. 3x faster than the one-filter-row
-    // kernel on every 3x3 / 4x4 / 5x5 shape of the training steps (tools/probe_wgrad_shapes.py, profiles/r03/wgrad_variants.md)
-    // except the widest 5x5 layers on large tiles -- 32-wide cout windows there (see below), steps too short for their
-    // barrier: 3.07 against 2.55 ms at 128 -> 128 on 16 tiles of 256^2 (0.25 against 0.30 ms on tiles of 64^2)
-    const bool wide5 = kh == 5 && cout > 32 && cin > 32 && (size_t)n * h * w > (size_t)16 * 128 * 128;
-    if (MPG_WG_RING && kh == kw && (kh == 3 || kh == 4 || kh == 5) && !wide5) {
+    // all filter rows of a tile in one block, x rows in an LDS ring (wgrad_ring_kernel): 1.02 .. 3x faster than the
+    // one-filter-row kernel on every 3x3 / 4x4 / 5x5 shape of the training steps (tools/probe_wgrad_shapes.py,
+    // profiles/r03/wgrad_variants.md); other filter shapes stay on that kernel
+    if (MPG_WG_RING && kh == kw && (kh == 3 || kh == 4 || kh == 5)) {
         const int nco = (cout + 31) / 32;
-        // cout tiles per window: as many as leave <= 6 accumulator tiles per wave (5x5 with a 64-wide window is 7 on two of
-        // the waves and compiled to 28 spilled registers: 32-wide windows there, 4 tiles on one wave, 3 on the others)
-        const int cotw = kh == 3 ? (nco >= 3 ? 4 : nco) : (kh == 4 && nco >= 2 ? 2 : 1);
+        // cout tiles per window: as many as the registers of a wave take beside its windows (5x5 with a 64-wide window is 7
+        // tiles on two of the waves and compiled to 28 spilled registers: 32-wide windows there, 4 tiles on one wave, 3 on
+        // the others; 3x3 with a 128-wide window at three products: 7 spilled registers, 64-wide there)
+        const int cotw = kh == 3 ? (nco >= 3 && prec != MPG_PREC_F16X3 ? 4 : (nco >= 2 ? 2 : 1)) : (kh == 4 && nco >= 2 ? 2 : 1);
         WrArgs a;
         a.xg = xg; a.dg = dg; a.x_amax = x_amax; a.d_amax = d_amax; a.zeros = zeros; a.dw = dw;
         a.n = n; a.h = h; a.w = w;
@@ -831,7 +855,8 @@ int wgrad_launches(hipStream_t s, const char* xg, const char* dg, const float* x
 #define MPG_WR(K, C)                                                                      \
     if (kh == K && cotw == C)                                                             \
         le = prec == MPG_PREC_F16X3 ? launch_ring<K, K, C, 3>(s, a, blocks) : launch_ring<K, K, C, 1>(s, a, blocks)
-        MPG_WR(3, 1); MPG_WR(3, 2); MPG_WR(3, 4); MPG_WR(4, 1); MPG_WR(4, 2); MPG_WR(5, 1);
+        MPG_WR(3, 1); MPG_WR(3, 2); MPG_WR(4, 1); MPG_WR(4, 2); MPG_WR(5, 1);
+        if (kh == 3 && cotw == 4) le = launch_ring<3, 3, 4, 1>(s, a, blocks);
 #undef MPG_WR
         if (le != hipSuccess) return mpg::hip_check(le, "wgrad_ring_kernel");
         MPG_LAUNCH_CHECK("mpg_conv2d_wgrad (ring)");
