@@ -77,7 +77,7 @@ def wgrad_roofline(device, tile_high, batch, iters=10, k=5, c=128):
         with open(pmc) as f:
             per = json.load(f)["per_kernel_per_call"]
         traffic = sum(v["hbm_read_bytes"] + v["hbm_write_bytes"] for kname, v in per.items() if "absmax" not in kname)
-    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_g8 %dx%d %d->%d (scaled G8 conversion of dy + wgrad_mfma_kernel; x = the forward "
+    return {"bound": "mfma", "kernel": "mpg_conv2d_wgrad_g8 %dx%d %d->%d (scaled G8 conversion of dy + wgrad_ring_kernel; x = the forward "
                                        "launch's G8 operand), %d tiles of %d^2" % (k, k, c, c, batch, tile_high),
             "achieved": round(ach, 2), "peak": DENSE_F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / DENSE_F16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "launch_ms": round(ms, 4),

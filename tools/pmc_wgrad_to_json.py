@@ -18,14 +18,14 @@ def table(d, counter):
 f, w = table("pmc_wgrad_fetch", "FETCH_SIZE"), table("pmc_wgrad_write", "WRITE_SIZE")
 out = {"call": "the weight gradient as the training step issues it: 5x5 128->128, 16 tiles of 256^2; x = the forward launch's G8 operand "
                "(512 MiB, no pass of its own), dy fp32 NHWC 512 MiB -> G8 scaled by max |dy| (one conversion shared with the data "
-               "gradient, listed), mpg_conv2d_wgrad_g8 MPG_PREC_F16X3",
+               "gradient, listed), mpg_conv2d_wgrad_g8 MPG_PREC_F16X3 (wgrad_ring_kernel<5,5,1,3>)",
        "command": "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/roofline_probe_wgrad.py %d ; same with "
                   "--pmc WRITE_SIZE (separate passes); summarised by tools/pmc_wgrad_to_json.py" % calls,
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams -> doubled; WRITE_SIZE as counted",
        "per_kernel_per_call": {}, "calls": calls}
 tot = 0.0
 for k in sorted(set(f) | set(w)):
-    if not any(t in k for t in ("absmax", "to_g8", "wgrad_mfma")):
+    if not any(t in k for t in ("absmax", "to_g8", "wgrad_")):
         continue
     rd = f.get(k, (0, 0))[0] * 1024 * 2 / calls
     wr = w.get(k, (0, 0))[0] * 1024 / calls

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launches the dominant kernel of the training benches (matrix-core weight gradient of a 5x5 128->128 conv on 16
-tiles of 256^2: the scaled G8 conversion of dy that the data gradient shares + wgrad_mfma_kernel<5,2,3>) a few times; run under
+tiles of 256^2: the scaled G8 conversion of dy that the data gradient shares + wgrad_ring_kernel<5,5,1,3>) a few times; run under
 `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes) to get the HBM traffic per kernel."""
 import os
 import sys
