@@ -80,6 +80,10 @@ WG_MFMA_CASES = [
     (2, 16, 16, 8, 1, 5), (2, 16, 16, 1, 2, 5), (2, 12, 12, 9, 17, 1), (2, 8, 8, 128, 256, 4),
     (1, 32, 64, 128, 128, 5), (2, 16, 40, 64, 96, 5), (1, 8, 300, 33, 65, 3), (2, 64, 64, 8, 32, 5),
     (2, 16, 16, 200, 40, 1), (1, 16, 16, 40, 72, 4),
+    # the ring form (all filter rows of a tile in one block): ragged row ranges (20 rows in ranges of 10), ragged columns
+    # (70 = one chunk of 64 + 6), channel groups and cout tiles that do not exist, a ring that wraps many times
+    (1, 20, 70, 40, 40, 5), (1, 9, 17, 8, 8, 3), (2, 33, 65, 130, 70, 3), (1, 16, 48, 32, 64, 4), (1, 70, 20, 16, 96, 5),
+    # shapes that stay on the one-filter-row kernel: 1 x 1 and non-square filters are not in this list (kh == kw here)
 ]
 
 
@@ -121,6 +125,20 @@ def test_conv_wgrad_g8(case, prec):
     got = train_ops.conv2d_wgrad_g8(ops.to_g8(x), ops.to_g8(dy, amax=am), k, k, wscale, prec, None, am)
     # the row ranges are combined with fp32 atomics in launch order: equal up to that reordering
     assert rel(got.cpu().numpy(), ref.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 5), (7, 3), (1, 5), (5, 1), (2, 4), (6, 3)])
+def test_conv_wgrad_mfma_other_filter_shapes(shape):
+    """non-square and 1-wide filters stay on the one-filter-row kernel (square 3x3 / 4x4 / 5x5 run the ring form)"""
+    from mpgan_amd import train_ops
+    kh, kw = shape
+    rng = np.random.default_rng(100 * kh + kw)
+    x = rng.standard_normal((2, 18, 37, 24)).astype(np.float32)
+    dy = (rng.standard_normal((2, 18, 37, 40)) * 1e-5).astype(np.float32)
+    wt = rng.standard_normal((kh, kw, 24, 40)).astype(np.float32)
+    _, dw_ref = ref_conv_grads(x, wt, dy, 1, 0.05)
+    dw = train_ops.conv2d_wgrad_mfma(dev(x), dev(dy), kh, kw, 0.05, 3).cpu().numpy()
+    assert dw.shape == dw_ref.shape and rel(dw, dw_ref) < 2e-6
 
 
 def test_conv_wgrad_mfma_zero_and_constant():
