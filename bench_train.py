@@ -41,6 +41,11 @@ def fwd_flops_per_tile(tile_high, c):
     return g, d
 
 
+DTYPES = {3: "f16x3 (fp16 hi/lo split, three MFMA products, fp32 accumulate)",
+          2: "forward / data gradient: f16+2xbf6 (MPG_PREC_F16F6) where the kernels cover the shape, else f16x3; weight gradient f16x3; "
+             "fp32 accumulate"}
+
+
 def wgrad_roofline(device, tile_high, batch, iters=10, k=5, c=128):
     """the matrix-core weight gradient of the widest conv of the step on one batch (4x: resBlock 1's 5x5
     128->128; 8x net1: a 3x3 64->64 conv of the 4x level)"""
@@ -123,6 +128,9 @@ def main():
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prec", type=int, default=3, choices=(2, 3),
+                    help="3: fp32-grade convolutions (default, what the parity tests hold the step to); 2: forward and "
+                         "data-gradient convolutions at MPG_PREC_F16F6 where the kernels cover the shape (weight gradients stay at 3)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch-timeout", type=float, default=3000.0)
@@ -158,7 +166,8 @@ def main():
         if rank == 0:
             print(json.dumps(out))
         return
-    tr = Trainer4x(tileSizeLow=args.tile, upRes=4, n_inputChannels=args.channels, batch_norm=True, device=str(dev), comm=comm)
+    tr = Trainer4x(tileSizeLow=args.tile, upRes=4, n_inputChannels=args.channels, batch_norm=True, device=str(dev), comm=comm,
+                   prec=args.prec)
     xs = torch.as_tensor(rng.random((args.batch, args.tile ** 2 * args.channels)).astype(np.float32), device=dev)
     ys = torch.as_tensor(rng.random((args.batch, (args.tile * 4) ** 2)).astype(np.float32), device=dev)
     step = tr.train_step if (args.eager or world > 1) else tr.train_step_graphed
@@ -171,7 +180,7 @@ def main():
         "metric": "training iterations/s, 4x GAN step (G+D fwd/bwd + Adam), %d tiles of %d^2 per GPU, %d channels" % (args.batch, th, args.channels),
         "value": round(1.0 / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x3 (fp16 hi/lo split, three MFMA products, fp32 accumulate)", "data": "synthetic",
+        "dtype": DTYPES[args.prec], "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: 4x training step, tileSize %d -> %d^2, batch %d, density+velocity, "
                                "batchNorm on, spatial discriminator, discRuns=genRuns=1" % (args.tile, th, args.batch),
                    "launch": "eager" if (args.eager or world > 1) else "hipGraph replay",
@@ -211,7 +220,7 @@ def bench_c5(args, comm, dev, rank, world, rng):
     from mpgan_amd.arch import Cfg8x
     from mpgan_amd.train import Trainer8x
     cfg = Cfg8x(tileSizeLow=args.tile, upRes=8, n_inputChannels=6, start_fms=256, max_fms=256)
-    tr = Trainer8x(cfg, device=str(dev), comm=comm)
+    tr = Trainer8x(cfg, device=str(dev), comm=comm, prec=args.prec)
     xs = torch.as_tensor(rng.random((args.batch, cfg.n_input)).astype(np.float32), device=dev)
     ys = torch.as_tensor(rng.random((args.batch, cfg.n_output)).astype(np.float32), device=dev)
     dt, (d, g) = timed(lambda a, b: tr.train_step(a, b, 3.0), (xs, ys), args, comm, dev)
@@ -221,7 +230,7 @@ def bench_c5(args, comm, dev, rank, world, rng):
                   "%d tiles of %d^2 per GPU" % (args.batch, th),
         "value": round(1.0 / dt, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16x3 (fp16 hi/lo split, three MFMA products, fp32 accumulate)", "data": "synthetic",
+        "dtype": DTYPES[args.prec], "data": "synthetic",
         "config": {"workload": "BASELINE configs[4] per GPU: multipassGAN-8x.py final stage (percentage 3.0), tileSize %d -> %d^2, "
                                "batch %d, firstNNArch, startFms 256, 6 input channels, WGAN-GP" % (args.tile, th, args.batch),
                    "parallelism": "dp%d" % world, "tiles_per_s": round(world * args.batch / dt, 1),

@@ -27,12 +27,28 @@ def _mfma_ok(kh, kw, width, stride):
     return stride == (1, 1) and kh <= 7 and kw <= 7 and width <= 512
 
 
+def _conv_prec(prec, kh, kw, cin, cout):
+    """the precision a forward / data-gradient convolution of the training step runs at when the trainer asks for `prec`:
+    MPG_PREC_F16F6 (the inference default: 1e-4-grade, 1.6x faster on the wide layers) where the kernels cover the shape and
+    the contraction is long enough to pay for it (the session's rule), else the fp32-grade three-product mode"""
+    if prec != ops.PREC_F16F6:
+        return prec
+    if kh * kw * cin > ops.F16F6_MIN_K and ops.f6_available(cout, [(kh, kw, cin)]):
+        return ops.PREC_F16F6
+    return ops.PREC_F16X3
+
+
+def _wgrad_prec(prec):
+    """weight gradients contract over pixels on fp16 hi/lo splits only: three products unless one is asked for"""
+    return prec if prec == ops.PREC_F16X1 else ops.PREC_F16X3
+
+
 def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None, keep=None):
     """conv2d_SAME(x, w * wscale) [+ bias, act] on the MFMA kernel, output channels in chunks of 128.
     rescale: x is a gradient (1e-4 .. 1e-8 in magnitude, below the fp16 normal range): it is split into
     fp16 hi/lo after a power-of-two scaling by its absolute maximum, and the sum is scaled back in the epilogue.
     keep: a list that receives the G8 form of x the kernel read (the weight gradient reads the same tensor)"""
-    cout = w.shape[3]
+    kh, kw, cin, cout = w.shape
     outs = []
     if not rescale:
         amax = None
@@ -42,7 +58,7 @@ def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, resc
     for c0 in range(0, cout, 128):
         c1 = min(cout, c0 + 128)
         wc = w if (c0 == 0 and c1 == cout) else w[..., c0:c1].contiguous()
-        pk = ops.pack_conv_weights(wc, wscale=wscale, prec=prec)
+        pk = ops.pack_conv_weights(wc, wscale=wscale, prec=_conv_prec(prec, kh, kw, cin, c1 - c0))
         bc = None if bias is None else (bias if (c0 == 0 and c1 == cout) else bias[c0:c1].contiguous())
         seg = ops.Segment(x, pk, pad_hi=pad_hi)
         if len(outs) == 0 and keep is not None:
@@ -125,10 +141,10 @@ class ConvLayerFn(torch.autograd.Function):
             d_g8 = ops.to_g8(d, 0, cout, ops.flavour_for(cfg["prec"]), amax=d_amax)
         if ctx.needs_input_grad[1]:
             if d_g8 is not None:
-                dw = train_ops.conv2d_wgrad_g8(x_g8, d_g8, kh, kw, wscale, cfg["prec"], None, d_amax)
+                dw = train_ops.conv2d_wgrad_g8(x_g8, d_g8, kh, kw, wscale, _wgrad_prec(cfg["prec"]), None, d_amax)
             elif wgrad_mm:
                 # x is the layer's forward input (an activation): split unscaled, no abs-max pass over it
-                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, cfg["prec"], d_amax,
+                dw = train_ops.conv2d_wgrad_mfma(x, d, kh, kw, wscale, _wgrad_prec(cfg["prec"]), d_amax,
                                                  train_ops.unit_amax(x.device))
             else:
                 dw = train_ops.conv2d_wgrad(x, d, kh, kw, stride, wscale)
@@ -171,7 +187,7 @@ def _conv_dgrad(dy, w, cfg, hw):
 
 def _conv_wgrad(x, dy, cfg, kh, kw):
     if train_ops.wgrad_mfma_ok(kh, kw, cfg["stride"]) and not cfg.get("fc"):
-        return train_ops.conv2d_wgrad_mfma(x, dy, kh, kw, cfg["wscale"], cfg["prec"])
+        return train_ops.conv2d_wgrad_mfma(x, dy, kh, kw, cfg["wscale"], _wgrad_prec(cfg["prec"]))
     return train_ops.conv2d_wgrad(x, dy, kh, kw, cfg["stride"], cfg["wscale"])
 
 
@@ -467,9 +483,10 @@ class TrainSession(object):
     def __init__(self, variables, graph=None, prec=ops.PREC_F16X3, bn_decay=0.999, device="cuda:0"):
         self.graph = graph or G.get_default_graph()
         self.vars = variables
-        if prec not in (ops.PREC_F16X3, ops.PREC_F16X1):
-            # the weight-gradient kernel contracts over pixels with fp16 hi/lo operands only
-            raise _lib.MpgError("training runs MPG_PREC_F16X3 (or F16X1); MPG_PREC_F16F6 is an inference mode")
+        if prec not in (ops.PREC_F16X3, ops.PREC_F16X1, ops.PREC_F16F6):
+            raise _lib.MpgError("training precision %r: MPG_PREC_F16X3 (default, fp32-grade), F16X1 or F16F6" % (prec,))
+        # F16F6: forward and data-gradient convolutions at the inference default where the kernels cover the shape
+        # (_conv_prec); the weight gradients contract over pixels with fp16 hi/lo operands and stay at three products
         self.prec = prec
         self.bn_decay = bn_decay
         self.device = torch.device(device)

@@ -1,0 +1,78 @@
+"""diagnostic: the gradient parity check of tests/test_train_gpu.py::test_gan4x_losses_and_gradients[4-True] repeated in
+one process; prints every repetition whose generator gradients are off, with per-tensor errors and the best-fit scale"""
+import math
+import sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+import torch
+import test_train_gpu as T
+TR = T.TR
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+import os
+from mpgan_amd import train_ops as _to, train as _tr
+if os.environ.get("ZERO_AMAX"):            # emulate a lost abs-max (scale 1) for the batch-norm backward of layers with that many channels
+    _cs = [int(v) for v in os.environ["ZERO_AMAX"].split(",")]
+    _bn = _to.bn_train_bwd
+    def _bn_zero(dy, x, mean, var, gamma, eps=1e-3, want_amax=False):
+        r = _bn(dy, x, mean, var, gamma, eps, want_amax)
+        if want_amax and x.shape[-1] in _cs and x.shape[1] == int(os.environ.get("ZERO_AMAX_H", x.shape[1])):
+            r[3].zero_()
+        return r
+    _to.bn_train_bwd = _bn_zero
+if os.environ.get("NO_WGRAD_MM"):          # fp32 vector-ALU weight gradients everywhere, no shared G8 of d
+    _to.wgrad_mfma_ok = lambda *a, **k: False
+if os.environ.get("NO_SHARE"):             # matrix weight gradients through the fp32 entry (own conversions), no shared G8
+    _orig = _tr._mfma_conv
+    def _no_keep(*a, **k):
+        k.pop("keep", None)
+        return _orig(*a, **k)
+    _tr._mfma_conv = _no_keep
+tr, p, xs, ys = T._trainer_and_oracle(8, 4, 4, True)
+Lr = TR.losses_4x(p, xs, ys, 8, 4, 4, batch_norm=True)
+rd = TR.grads(Lr["disc_loss"], p, "d_")
+rg = TR.grads(Lr["gen_loss_complete"], p, "g_")
+bad = 0
+first = None
+poison = len(sys.argv) > 2
+for it in range(reps):
+    if poison:       # hand the allocator blocks full of NaN (or a large finite value): whoever reads memory it did not write shows
+        val = float("nan") if sys.argv[2] == "nan" else float(sys.argv[2])
+        junk = [torch.full((n,), val, device="cuda:0") for n in [2 ** k for k in range(6, 25)] * 2]
+        del junk
+    L = tr.losses(xs, ys)
+    gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
+    gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+    cur = {"loss_d": L["disc_loss"].detach().clone(), "loss_g": L["gen_loss_complete"].detach().clone()}
+    for nme, g in list(zip(tr.opt_d.names, gd)) + list(zip(tr.opt_g.names, gg)):
+        cur[nme] = g.detach().clone()
+    if first is None:
+        first = cur
+    else:
+        diffs = []
+        for kk, v in cur.items():
+            r0 = first[kk]
+            e = float((v - r0).norm() / (r0.norm() + 1e-30))
+            if e > 2e-5:
+                diffs.append((kk.replace("generator/", "g:").replace("discriminator/", "d:"), float("%.1e" % e)))
+        if diffs:
+            print("rep %d vs rep 0: %s" % (it, diffs), flush=True)
+    for grp, names, got, want in (("d", tr.opt_d.names, gd, rd), ("g", tr.opt_g.names, gg, rg)):
+        num = den = dot = gg2 = 0.0
+        worst = []
+        for nme, g in zip(names, got):
+            if nme in T.BN_BIASES:
+                continue
+            w = want[nme]
+            gnp = g.cpu().numpy().astype(np.float64)
+            num += float(((gnp - w) ** 2).sum()); den += float((w ** 2).sum())
+            dot += float((gnp * w).sum()); gg2 += float((gnp ** 2).sum())
+            r = T.rel(gnp, w)
+            if r > 1e-4:
+                worst.append((nme.replace("generator/", "").replace("discriminator/", ""), float("%.2g" % r)))
+        err = math.sqrt(num / den)
+        if not (err <= 5e-5):
+            bad += 1
+            scale = dot / den
+            print("rep %d group %s: total %.2e, best-fit scale %.6f, cosine %.8f, %d tensors off: %s" % (
+                it, grp, err, scale, dot / math.sqrt(den * gg2), len(worst), worst[:40]), flush=True)
+print("repetitions %d, deviating %d" % (reps, bad))
