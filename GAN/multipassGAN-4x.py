@@ -51,7 +51,7 @@ for name, default in [
         ("saveMetaData", 0), ("use_spatialdisc", True), ("clamping", True), ("simLowLength", 64), ("simLowWidth", 64),
         ("simLowHeight", 64), ("overlappedpixel", 3), ("startIndex", 0), ("useAvgDepool", False), ("avgMode", 0),
         ("velScale", 1.0), ("upsamplingMode", 2), ("upsampledData", False), ("sliceMode", 0), ("interpMode", 1),
-        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0), ("prec", "2"),
+        ("genUni", False), ("setVelZero", False), ("upsampleFirst", True), ("synthWeights", 0), ("prec", "2"), ("trainPrec", "3"),
         ("deviceTiles", 1)]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
@@ -174,7 +174,7 @@ def train_main():
                         lambda2_l=tuple(float(P["lambda2_l%d" % i]) for i in (1, 2, 3, 4)),
                         weight_dld=float(P["weight_dld"]), bn_decay=float(P["bnDecay"]), seed=randSeed,
                         use_tempo=useTempoD, lambda_t=kt, adv_flag=int(P["adv_flag"]) > 0, clamping=int(P["clamping"]) > 0,
-                        lambda_t_l2=kt_l)
+                        lambda_t_l2=kt_l, prec=ops.parse_prec(P["trainPrec"]))
     if load_model_test >= 0:
         params = checkpoint.load(checkpoint.model_path(basePath, load_model_test, load_model_no))
         with torch.no_grad():

@@ -58,7 +58,7 @@ for name, default in [
         ("startingIter", 0), ("loadEmas", False), ("useVelInTDisc", False), ("upsampleMode", 1), ("lossScaling", False),
         ("stageIter", 25000), ("decayIter", 25000), ("maxFms", 256), ("use_wgan_gp", False), ("use_res_net", False),
         ("use_mb_stddev", False), ("deviceTiles", 1), ("use_LSGAN", False), ("startFms", 512), ("filterSize", 3), ("outNNTestNo", 17),
-        ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2), ("synthWeights", 0), ("prec", "2")]:
+        ("firstNNArch", False), ("gDrop", False), ("add_adj_idcs", False), ("gpu", 2), ("synthWeights", 0), ("prec", "2"), ("trainPrec", "3")]:
     P[name] = ph.getParam(name, default)
 ph.checkUnusedParams()
 
@@ -255,6 +255,7 @@ test_path, _ = ph.getNextTestPath(int(P["testPathStartNo"]), basePath)
 print("\nUsing parameters:\n" + ph.paramsToString())
 ph.writeParams(test_path + "params.json")
 
+from mpgan_amd import ops  # noqa: E402
 from mpgan_amd.arch import Cfg8x  # noqa: E402
 from mpgan_amd.train import Trainer8x  # noqa: E402
 
@@ -269,7 +270,7 @@ trainer = Trainer8x(cfg, device=device, learning_rate=learning_rate, beta1=float
                     weight_dld=float(P["weight_dld"]), use_wgan_gp=int(P["use_wgan_gp"]) > 0,
                     use_LSGAN=int(P["use_LSGAN"]) > 0, seed=randSeed, use_tempo=useTempoD, lambda_t=kt,
                     adv_flag=int(P["adv_flag"]) > 0, loss_scaling=int(P["lossScaling"]) > 0,
-                    adv_mode=int(P["adv_mode"]), batch_norm=int(P["batchNorm"]) > 0)
+                    adv_mode=int(P["adv_mode"]), batch_norm=int(P["batchNorm"]) > 0, prec=ops.parse_prec(P["trainPrec"]))
 if int(P["load_model_test"]) >= 0:
     params = checkpoint.load(checkpoint.model_path(basePath, int(P["load_model_test"]), int(P["load_model_no"])))
     with torch.no_grad():
