@@ -19,6 +19,23 @@ if os.environ.get("ZERO_AMAX"):            # emulate a lost abs-max (scale 1) fo
             r[3].zero_()
         return r
     _to.bn_train_bwd = _bn_zero
+TRACE = []
+if os.environ.get("TRACE"):                # checksums of every data-gradient convolution's operands and result, per repetition
+    from mpgan_amd import ops as _ops
+    _mc = _tr._mfma_conv
+    def _cs(t):
+        return float(t.double().abs().sum().item())
+    def _traced(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None, keep=None):
+        out = _mc(x, w, wscale, prec, bias, act, leak, pad_hi, rescale, amax, keep)
+        if rescale:
+            rec = {"shape": tuple(w.shape), "w": _cs(w), "out": _cs(out), "amax": float(amax.item()) if amax is not None else None}
+            if not isinstance(x, torch.Tensor):
+                rec["x_hi"] = _cs(x.buf[:, :, 0].float()); rec["x_lo"] = _cs(x.buf[:, :, 1].float())
+            else:
+                rec["x"] = _cs(x)
+            TRACE.append(rec)
+        return out
+    _tr._mfma_conv = _traced
 if os.environ.get("NO_WGRAD_MM"):          # fp32 vector-ALU weight gradients everywhere, no shared G8 of d
     _to.wgrad_mfma_ok = lambda *a, **k: False
 if os.environ.get("NO_SHARE"):             # matrix weight gradients through the fp32 entry (own conversions), no shared G8
@@ -42,6 +59,16 @@ for it in range(reps):
     L = tr.losses(xs, ys)
     gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
     gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+    trace_now = list(TRACE); del TRACE[:]
+    if it == 0:
+        trace0 = trace_now
+    elif trace_now:
+        def far(u, v):
+            return u is not None and abs(u - v) > 3e-5 * max(abs(u), abs(v), 1e-30)
+        for k, (a, b) in enumerate(zip(trace0, trace_now)):
+            d = {kk: (a[kk], b[kk]) for kk in a if kk != "shape" and far(a[kk], b[kk])}
+            if d:
+                print("rep %d: data-gradient convolution %d %s differs beyond 3e-5: %s" % (it, k, a["shape"], d), flush=True)
     cur = {"loss_d": L["disc_loss"].detach().clone(), "loss_g": L["gen_loss_complete"].detach().clone()}
     for nme, g in list(zip(tr.opt_d.names, gd)) + list(zip(tr.opt_g.names, gg)):
         cur[nme] = g.detach().clone()
