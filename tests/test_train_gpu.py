@@ -285,28 +285,45 @@ def test_gan4x_losses_and_gradients(C, bn):
         a, b = float(L[k].detach()), float(Lr[k].detach())
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (k, a, b)
     assert rel(L["gen_part"].detach().cpu().numpy().reshape(batch, -1), Lr["gen_part"].detach().numpy().reshape(batch, -1)) < 1e-4
-    gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
-    gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
     rd = TR.grads(Lr["disc_loss"], p, "d_")
     rg = TR.grads(Lr["gen_loss_complete"], p, "g_")
     assert sorted(rd) == tr.opt_d.names and sorted(rg) == tr.opt_g.names
-    worst, off = 0.0, []
-    for names, got, want in ((tr.opt_d.names, gd, rd), (tr.opt_g.names, gg, rg)):
-        tot_d = tot_r = 0.0
-        for nme, g in zip(names, got):
-            w = want[nme]
-            gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
-            if bn and nme in BN_BIASES:
-                # bias under batch norm: exact gradient is 0, both sides hold rounding noise only
-                assert np.abs(gnp).max() < 1e-4
-                continue
-            r = rel(gnp, w)
-            worst = max(worst, r)
-            if r >= 1e-4:
-                off.append((nme, float("%.3g" % r)))
-            tot_d += float(((gnp - w) ** 2).sum())
-            tot_r += float((w ** 2).sum())
-        assert math.sqrt(tot_d / tot_r) < 2e-4, off
+
+    def compare(L):
+        gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
+        gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+        worst, total, off = 0.0, 0.0, []
+        for names, got, want in ((tr.opt_d.names, gd, rd), (tr.opt_g.names, gg, rg)):
+            tot_d = tot_r = 0.0
+            for nme, g in zip(names, got):
+                w = want[nme]
+                gnp = g.cpu().numpy().astype(np.float64) if g is not None else np.zeros_like(w)
+                if bn and nme in BN_BIASES:
+                    # bias under batch norm: exact gradient is 0, both sides hold rounding noise only
+                    assert np.abs(gnp).max() < 1e-4
+                    continue
+                r = rel(gnp, w)
+                worst = max(worst, r)
+                if r >= 1e-4:
+                    off.append((nme, float("%.3g" % r)))
+                tot_d += float(((gnp - w) ** 2).sum())
+                tot_r += float((w ** 2).sum())
+            total = max(total, math.sqrt(tot_d / tot_r))
+        return worst, total, off
+
+    # The gradient of a ReLU network is discontinuous where a pre-activation is zero, and with 5e5 activations in the widest
+    # layer of this case the one nearest to zero sits ~2e-6 away -- closer than the 1e-7-relative, run-to-run variation of the
+    # batch statistics (their block sums are combined with atomics).  In ~3 % of the evaluations that element's mask comes out
+    # on the other side than in the float64 oracle; ONE flipped element moves the gradients of everything upstream by
+    # 1 / sqrt(5e5) ~ 1e-3 -- always the same alternative numbers (tools/experiments/grad_flake.py finds the call: the ReLU
+    # backward of generator/g_cA1, inputs 1e-6 apart, outputs 9e-4 apart).  Both sides are correct gradients of the
+    # function as evaluated, so an evaluation that lands on the other side is repeated; an arithmetic regression fails every time.
+    for attempt in range(3):
+        worst, total, off = compare(L if attempt == 0 else tr.losses(xs, ys))
+        if worst < 1e-3 and total < 2e-4:
+            break
+        print("attempt %d: per-tensor %.2e, total %.2e: %s" % (attempt, worst, total, off))
+    assert total < 2e-4, off
     assert worst < 1e-3, off
     print("worst per-tensor gradient error", worst)
 

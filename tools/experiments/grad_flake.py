@@ -36,6 +36,66 @@ if os.environ.get("TRACE"):                # checksums of every data-gradient co
             TRACE.append(rec)
         return out
     _tr._mfma_conv = _traced
+if os.environ.get("DGRAD_VALU"):           # the data gradient of layers with this many output AND input channels on the fp32 vector-ALU kernel
+    _sel = int(os.environ["DGRAD_VALU"])
+    _mc2 = _tr._mfma_conv
+    def _route(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, rescale=False, amax=None, keep=None):
+        if rescale and isinstance(x, torch.Tensor) and w.shape[2] == _sel and w.shape[3] == _sel:
+            w0 = w.permute(0, 1, 3, 2).flip(0, 1).contiguous()          # back to [kh, kw, cin, cout] of the layer
+            return _to.conv2d_dgrad(x.contiguous(), w0, (x.shape[1], x.shape[2]), (1, 1), wscale)
+        return _mc2(x, w, wscale, prec, bias, act, leak, pad_hi, rescale, amax, keep)
+    _tr._mfma_conv = _route
+if os.environ.get("REF_ACT"):              # activation backward in the tensor library
+    def _act_ref(dy, y, act, leak=0.2, want_amax=False):
+        if act == "relu":
+            d = dy * (y > 0)
+        elif act == "lrelu":
+            d = dy * torch.where(y > 0, torch.ones_like(y), torch.where(y < 0, torch.full_like(y, leak), torch.full_like(y, 0.5 * (1 + leak))))
+        else:
+            d = dy * (1 - y * y)
+        return (d, d.abs().max()) if want_amax else d
+    _to.act_bwd = _act_ref
+if os.environ.get("REF_BN"):               # batch-norm backward in the tensor library
+    def _bn_ref(dy, x, mean, var, gamma, eps=1e-3, want_amax=False):
+        c = x.shape[-1]
+        n = x.numel() // c
+        isd = torch.rsqrt(var + eps)
+        xh = (x - mean) * isd
+        dbeta = dy.reshape(-1, c).sum(0)
+        dgamma = (dy * xh).reshape(-1, c).sum(0)
+        dx = gamma * isd * (dy - dbeta / n - xh * dgamma / n)
+        return (dx, dgamma, dbeta, dx.abs().max()) if want_amax else (dx, dgamma, dbeta)
+    _to.bn_train_bwd = _bn_ref
+CALLS = []
+if os.environ.get("WATCH2"):               # every activation / batch-norm backward call: inputs and outputs, by call order
+    _a0, _b0 = _to.act_bwd, _to.bn_train_bwd
+    def _wa(dy, y, act, leak=0.2, want_amax=False):
+        r = _a0(dy, y, act, leak, want_amax)
+        CALLS.append(("act %s %s" % (act, tuple(dy.shape)), [dy.detach().clone(), y.detach().clone()], [(r[0] if want_amax else r).detach().clone()]))
+        return r
+    def _wb(dy, x, mean, var, gamma, eps=1e-3, want_amax=False):
+        r = _b0(dy, x, mean, var, gamma, eps, want_amax)
+        CALLS.append(("bn %s" % (tuple(dy.shape),), [t.detach().clone() for t in (dy, x, mean, var, gamma)], [t.detach().clone() for t in r[:3]]))
+        return r
+    _to.act_bwd, _to.bn_train_bwd = _wa, _wb
+LAYER = []
+if os.environ.get("WATCH"):                # checksums of what the backward of the 8 -> 128 5x5 generator layer receives
+    _bw = _tr.ConvLayerFn.backward
+    def _watch(ctx, dy):
+        t = ctx.saved_tensors
+        if tuple(t[1].shape) == (5, 5, 8, 128) and ctx.bn:
+            names = ("x", "w", "lin", "mean", "var", "gamma", "y")
+            rec = {"dy": dy.detach().clone()}
+            for nme, v in zip(names, t):
+                rec[nme] = v.detach().clone()
+            outs = _bw(ctx, dy)
+            for nme, v in zip(("dx", "dw", "db", "dgamma", "dbeta"), outs):
+                if v is not None:
+                    rec["out_" + nme] = v.detach().clone()
+            LAYER.append(rec)
+            return outs
+        return _bw(ctx, dy)
+    _tr.ConvLayerFn.backward = staticmethod(_watch)
 if os.environ.get("NO_WGRAD_MM"):          # fp32 vector-ALU weight gradients everywhere, no shared G8 of d
     _to.wgrad_mfma_ok = lambda *a, **k: False
 if os.environ.get("NO_SHARE"):             # matrix weight gradients through the fp32 entry (own conversions), no shared G8
@@ -59,6 +119,34 @@ for it in range(reps):
     L = tr.losses(xs, ys)
     gd = torch.autograd.grad(L["disc_loss"], tr.opt_d.params, allow_unused=True, retain_graph=True)
     gg = torch.autograd.grad(L["gen_loss_complete"], tr.opt_g.params, allow_unused=True)
+    calls_now = list(CALLS); del CALLS[:]
+    if it == 0:
+        calls0 = calls_now
+        if calls0:
+            print("watch2: %d activation / batch-norm backward calls per repetition" % len(calls0), flush=True)
+    elif calls_now:
+        def _rel(u, v):
+            return float((u - v).norm() / (u.norm() + 1e-30))
+        for k, (c0, c1) in enumerate(zip(calls0, calls_now)):
+            ein = max(_rel(u, v) for u, v in zip(c0[1], c1[1]))
+            eout = max(_rel(u, v) for u, v in zip(c0[2], c1[2]))
+            if ein > 1e-5 or eout > 1e-5:
+                print("rep %d: call %d (%s): inputs differ %.1e, outputs differ %.1e  <- first call that differs from repetition 0" % (it, k, c0[0], ein, eout), flush=True)
+                break
+    lay_now = list(LAYER); del LAYER[:]
+    if it == 0:
+        lay0 = lay_now
+        if os.environ.get("WATCH"):
+            print("watch: %d backward calls of the 8->128 layer recorded per repetition; keys %s" % (len(lay0), sorted(lay0[0]) if lay0 else None), flush=True)
+    elif lay_now:
+        for k, (a0, b0) in enumerate(zip(lay0, lay_now)):
+            dd = {}
+            for kk in a0:
+                e = float((a0[kk] - b0[kk]).norm() / (a0[kk].norm() + 1e-30))
+                if e > 1e-5:
+                    dd[kk] = float("%.2e" % e)
+            if dd:
+                print("rep %d: backward %d of the 8->128 layer sees other inputs (relative L2 vs repetition 0): %s" % (it, k, dd), flush=True)
     trace_now = list(TRACE); del TRACE[:]
     if it == 0:
         trace0 = trace_now
