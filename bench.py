@@ -182,6 +182,7 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
     ms_rand = _time_events(launch, iters, device, torch)
     ms = ms_inpipe if ms_inpipe is not None else (ms_pipe if ms_pipe is not None else ms_rand)
     achieved = flops / (ms * 1e-3) / 1e12
+    board = board_under_load(lambda: ops.conv2d_fused(**call) if call is not None else launch(), device, torch)
     # HBM bytes per launch of this very launch from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     # per MI355X_MICROARCH.md + WRITE_SIZE); null for other modes
     traffic = src = None
@@ -208,8 +209,51 @@ def dominant_kernel_roofline(gen2, x_batch, device, prec, iters=20, pipeline_pas
         "launch_ms_replay": round(ms_pipe, 4) if ms_pipe is not None else None,
         "launch_ms_random": round(ms_rand, 4),
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+        "board_under_this_launch": board,
         "mfma_products_per_mac": {3: "3 fp16", 2: "1 fp16 + 2 bf6 (MX e3m2, K=64 in the cycles of one fp16 K=16): 1.5 fp16-equivalent units", 1: "1 fp16"}[prec],
     }
+
+
+def board_under_load(fn, device, torch, secs=1.5):
+    """package power and shader clock (rocm-smi, polled from a thread) while `fn` is launched back to back for `secs`: the
+    layer kernels run at the board's power limit, and the clock is what the limit leaves (profiles/r03/power_clocks.txt);
+    None where rocm-smi is not there or prints something else"""
+    import re
+    import subprocess
+    import threading
+    rows, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", "0", "-P", "-c", "--csv"], capture_output=True, text=True, timeout=5).stdout
+                rows.append(out.strip().splitlines()[-1])
+            except Exception:                      # noqa: BLE001 -- a probe, never a reason to fail the bench
+                return
+            time.sleep(0.2)
+    try:
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        t0 = time.time()
+        while time.time() - t0 < secs:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(device)
+        stop.set()
+        th.join(timeout=6)
+        clk, pw = [], []
+        for r in rows[1:]:                          # the first sample may predate the load
+            f = r.split(",")
+            m = [int(v) for v in re.findall(r"\((\d+)Mhz\)", r)]
+            if len(m) >= 3 and f[-1].replace(".", "", 1).isdigit():
+                clk.append(m[2])
+                pw.append(float(f[-1]))
+        if not clk:
+            return None
+        return {"sclk_mhz": int(sum(clk) / len(clk)), "package_power_w": round(sum(pw) / len(pw), 1), "samples": len(clk),
+                "source": "rocm-smi -P -c polled while the launch replays back to back for %.1f s" % secs}
+    except Exception:                              # noqa: BLE001
+        return None
 
 
 def train_c3_block(device, steps=20, warmup=3):
