@@ -311,6 +311,15 @@ int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, flo
 int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
                      const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
                      float* batch_var, float* moving_mean, float* moving_var, float decay);
+/* The same with the blocks' partial sums kept in `partials` (>= mpg_bn_partials_floats(c) floats of device memory) and
+ * added in block order instead of by atomics: the batch statistics -- and with them every ReLU mask of the step -- are
+ * then the same bits on every run (a pre-activation within 1e-6 of zero otherwise changes side now and then, and one
+ * flipped mask element moves the gradients upstream of it by 1 / sqrt(elements): DESIGN section 10). */
+size_t mpg_bn_partials_floats(int c);
+int mpg_bn_train_fwd_ordered(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
+                             const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
+                             float* batch_var, float* moving_mean, float* moving_var, float decay, float* partials,
+                             size_t partials_floats);
 /* gradient of the normalisation above (dy is taken before the activation).  amax (may be NULL) receives max |dx|:
  * the data- and weight-gradient convolutions that consume dx scale it by a power of two before the fp16 split
  * (mpg_absmax would re-read the tensor for it). */

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
                                                        size_t npix, int c, int lanes, const float* __restrict__ aux0,
                                                        const float* __restrict__ aux1, float inv_n, float eps,
                                                        float* __restrict__ out0, float* __restrict__ out1,
-                                                       size_t pix_per_block) {
+                                                       size_t pix_per_block, float* __restrict__ partials) {
     __shared__ float red0[BLK];
     __shared__ float red1[BLK];
     const int tid = threadIdx.x;
@@ -203,8 +203,13 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const float* __restrict__
     __syncthreads();
     if (row == 0 && ch < c) {
         for (int r = 1; r < ppi; ++r) { s0 += red0[r * lanes + lane]; s1 += red1[r * lanes + lane]; }
-        atomicAdd(out0 + ch, s0);
-        if (MODE == 2 || MODE == 3) atomicAdd(out1 + ch, s1);
+        if (partials != nullptr) {           // ordered form: the block's sums are kept, bn_finalize_kernel adds them in block order
+            partials[((size_t)blockIdx.x * c + ch) * 2] = s0;
+            partials[((size_t)blockIdx.x * c + ch) * 2 + 1] = s1;
+        } else {
+            atomicAdd(out0 + ch, s0);
+            if (MODE == 2 || MODE == 3) atomicAdd(out1 + ch, s1);
+        }
     }
 }
 
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void chan_sum4_kernel(const float* __restrict_
                                                         int c, int lanes, const float* __restrict__ aux0,
                                                         const float* __restrict__ aux1, float inv_n, float eps,
                                                         float* __restrict__ out0, float* __restrict__ out1,
-                                                        size_t pix_per_block) {
+                                                        size_t pix_per_block, float* __restrict__ partials) {
     __shared__ float4 red0[BLK];
     __shared__ float4 red1[BLK];
     const int tid = threadIdx.x;
@@ -270,16 +275,21 @@ __global__ __launch_bounds__(256) void chan_sum4_kernel(const float* __restrict_
             t0.x += u0.x; t0.y += u0.y; t0.z += u0.z; t0.w += u0.w;
             t1.x += u1.x; t1.y += u1.y; t1.z += u1.z; t1.w += u1.w;
         }
-        atomicAdd(out0 + ch, t0.x); atomicAdd(out0 + ch + 1, t0.y); atomicAdd(out0 + ch + 2, t0.z); atomicAdd(out0 + ch + 3, t0.w);
-        if (MODE == 2 || MODE == 3) {
-            atomicAdd(out1 + ch, t1.x); atomicAdd(out1 + ch + 1, t1.y); atomicAdd(out1 + ch + 2, t1.z); atomicAdd(out1 + ch + 3, t1.w);
+        if (partials != nullptr) {
+            float* pp = partials + ((size_t)blockIdx.x * c + ch) * 2;
+            pp[0] = t0.x; pp[1] = t1.x; pp[2] = t0.y; pp[3] = t1.y; pp[4] = t0.z; pp[5] = t1.z; pp[6] = t0.w; pp[7] = t1.w;
+        } else {
+            atomicAdd(out0 + ch, t0.x); atomicAdd(out0 + ch + 1, t0.y); atomicAdd(out0 + ch + 2, t0.z); atomicAdd(out0 + ch + 3, t0.w);
+            if (MODE == 2 || MODE == 3) {
+                atomicAdd(out1 + ch, t1.x); atomicAdd(out1 + ch + 1, t1.y); atomicAdd(out1 + ch + 2, t1.z); atomicAdd(out1 + ch + 3, t1.w);
+            }
         }
     }
 }
 
 template <int MODE>
-void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix, int c, const float* aux0,
-                     const float* aux1, float inv_n, float eps, float* out0, float* out1) {
+int launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix, int c, const float* aux0,
+                    const float* aux1, float inv_n, float eps, float* out0, float* out1, float* partials = nullptr) {
     if (c >= 16 && (c % 4) == 0 && (((uintptr_t)a) & 15) == 0 && (x == nullptr || (((uintptr_t)x) & 15) == 0)) {
         int lanes = 1;
         while (lanes < c / 4 && lanes < BLK) lanes <<= 1;
@@ -292,8 +302,8 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
         const size_t ppb = (npix + blocks - 1) / blocks;
         blocks = (npix + ppb - 1) / ppb;
         hipLaunchKernelGGL((chan_sum4_kernel<MODE>), dim3((unsigned)blocks, cblocks), dim3(BLK), 0, s, a, x, npix, c, lanes,
-                           aux0, aux1, inv_n, eps, out0, out1, ppb);
-        return;
+                           aux0, aux1, inv_n, eps, out0, out1, ppb, partials);
+        return (int)blocks;
     }
     int lanes = 1;
     while (lanes < c && lanes < BLK) lanes <<= 1;
@@ -305,7 +315,33 @@ void launch_chan_sum(hipStream_t s, const float* a, const float* x, size_t npix,
     const size_t ppb = (npix + blocks - 1) / blocks;
     blocks = (npix + ppb - 1) / ppb;
     hipLaunchKernelGGL((chan_sum_kernel<MODE>), dim3((unsigned)blocks, cblocks), dim3(BLK), 0, s, a, x, npix, c, lanes,
-                       aux0, aux1, inv_n, eps, out0, out1, ppb);
+                       aux0, aux1, inv_n, eps, out0, out1, ppb, partials);
+    return (int)blocks;
+}
+constexpr int CHAN_SUM_MAX_BLOCKS = 1024;       // pixel blocks of either kernel (the size of a `partials` buffer: blocks x c x 2)
+
+// The ordered form of the sums: the blocks' partial sums ([block][channel][2]) added in a FIXED order -- 16 interleaved runs
+// of blocks per channel, then the 16 runs in sequence -- so that the result does not depend on the order the blocks ran in
+// (atomics: it does, at 1e-7 relative, enough to flip a ReLU mask element next to zero now and then).
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float2* __restrict__ partials, int nblocks, int c,
+                                                           float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ float2 red[256];
+    const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
+    const int ch = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (ch < c)
+        for (int b = seg; b < nblocks; b += 16) {
+            const float2 p = partials[(size_t)b * c + ch];
+            s0 += p.x;
+            s1 += p.y;
+        }
+    red[tid] = make_float2(s0, s1);
+    __syncthreads();
+    if (seg == 0 && ch < c) {
+        for (int k = 1; k < 16; ++k) { s0 += red[k * 16 + cl].x; s1 += red[k * 16 + cl].y; }
+        out0[ch] = s0;
+        out1[ch] = s1;
+    }
 }
 
 // sums -> batch mean / biased variance, and the moving averages of tf.contrib batch_norm
@@ -932,9 +968,31 @@ extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix,
     MPG_LAUNCH_CHECK("chan_sum_kernel");
 }
 
+extern "C" size_t mpg_bn_partials_floats(int c) { return c >= 1 ? (size_t)CHAN_SUM_MAX_BLOCKS * c * 2 : 0; }
+
+static int bn_train_fwd_impl(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma, const float* beta,
+                             float eps, int act, float leak, float* y, float* batch_mean, float* batch_var, float* moving_mean,
+                             float* moving_var, float decay, float* partials);
+
 extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
                                 const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
                                 float* batch_var, float* moving_mean, float* moving_var, float decay) {
+    return bn_train_fwd_impl(stream, x, npix, c, gamma, beta, eps, act, leak, y, batch_mean, batch_var, moving_mean, moving_var,
+                             decay, nullptr);
+}
+
+extern "C" int mpg_bn_train_fwd_ordered(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma,
+                                        const float* beta, float eps, int act, float leak, float* y, float* batch_mean,
+                                        float* batch_var, float* moving_mean, float* moving_var, float decay, float* partials,
+                                        size_t partials_floats) {
+    MPG_REQUIRE(partials != nullptr && partials_floats >= mpg_bn_partials_floats(c), "mpg_bn_train_fwd_ordered: partials buffer too small");
+    return bn_train_fwd_impl(stream, x, npix, c, gamma, beta, eps, act, leak, y, batch_mean, batch_var, moving_mean, moving_var,
+                             decay, partials);
+}
+
+static int bn_train_fwd_impl(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma, const float* beta,
+                             float eps, int act, float leak, float* y, float* batch_mean, float* batch_var, float* moving_mean,
+                             float* moving_var, float decay, float* partials) {
     MPG_REQUIRE(x && gamma && beta && y && batch_mean && batch_var, "mpg_bn_train_fwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_fwd: bad shape");
     MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_bn_train_fwd: bad activation %d", act);
@@ -954,7 +1012,10 @@ extern "C" int mpg_bn_train_fwd(mpg_stream_t stream, const float* x, size_t npix
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
                        moving_mean, moving_var, decay, (const float*)nullptr, (size_t)0);
 #else
-    launch_chan_sum<3>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, batch_var);
+    const int nb = launch_chan_sum<3>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, batch_mean, batch_var, partials);
+    if (partials != nullptr)
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 15) / 16), dim3(256), 0, s, (const float2*)partials, nb, c, batch_mean,
+                           batch_var);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(grid_for(c)), dim3(BLK), 0, s, batch_mean, batch_var, c, inv_n,
                        moving_mean, moving_var, decay, x, npix);
 #endif

@@ -119,9 +119,13 @@ def bn_train_fwd(x, gamma, beta, eps=1e-3, act=None, leak=0.2, moving_mean=None,
     mean, var = stats[0], stats[1]
     mm = _dev(moving_mean, "moving_mean") if moving_mean is not None else None
     mv = _dev(moving_var, "moving_var") if moving_var is not None else None
-    _lib.check(lib.mpg_bn_train_fwd(_stream(), _ptr(x), x.numel() // c, c, _ptr(_cont(gamma, "gamma")),
-                                    _ptr(_cont(beta, "beta")), float(eps), _lib.act_id(act), leak, _ptr(y), _ptr(mean),
-                                    _ptr(var), _ptr(mm), _ptr(mv), float(decay)), "mpg_bn_train_fwd")
+    # block sums added in block order, not by atomics: the statistics (and every ReLU mask behind them) are run-to-run stable
+    nfl = lib.mpg_bn_partials_floats(c)
+    partials = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_bn_train_fwd_ordered(_stream(), _ptr(x), x.numel() // c, c, _ptr(_cont(gamma, "gamma")),
+                                            _ptr(_cont(beta, "beta")), float(eps), _lib.act_id(act), leak, _ptr(y), _ptr(mean),
+                                            _ptr(var), _ptr(mm), _ptr(mv), float(decay), _ptr(partials), nfl),
+               "mpg_bn_train_fwd_ordered")
     return y, mean, var
 
 
