@@ -326,6 +326,11 @@ int mpg_bn_train_fwd_ordered(mpg_stream_t stream, const float* x, size_t npix, i
 int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
                      const float* batch_mean, const float* batch_var, const float* gamma, float eps,
                      float* dx, float* dgamma, float* dbeta, float* amax);
+/* ... with the blocks' partial sums of dbeta / dgamma kept in `partials` (mpg_bn_partials_floats(c) floats) and added in a
+ * fixed order, as mpg_bn_train_fwd_ordered does for the statistics */
+int mpg_bn_train_bwd_ordered(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
+                             const float* batch_mean, const float* batch_var, const float* gamma, float eps,
+                             float* dx, float* dgamma, float* dbeta, float* amax, float* partials, size_t partials_floats);
 /* dx = dy * act'(.) written through the activation OUTPUT y (relu, lrelu GAN.py:733-737, tanh); amax as above */
 int mpg_act_bwd(mpg_stream_t stream, const float* dy, const float* y, size_t n, int act, float leak, float* dx,
                 float* amax);

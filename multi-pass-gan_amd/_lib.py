@@ -141,6 +141,7 @@ PROTOTYPES = {
     "mpg_bn_partials_floats": (_Z, [_I]),
     "mpg_bn_train_fwd_ordered": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _F, _P, _Z]),
     "mpg_bn_train_bwd": (_I, [_P, _P, _P, _Z, _I, _P, _P, _P, _F, _P, _P, _P, _P]),
+    "mpg_bn_train_bwd_ordered": (_I, [_P, _P, _P, _Z, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _Z]),
     "mpg_act_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P, _P]),
     "mpg_pixel_norm_bwd": (_I, [_P, _P, _P, _Z, _I, _F, _P]),
     "mpg_resize_nearest_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I]),

@@ -1033,9 +1033,27 @@ static int bn_train_fwd_impl(mpg_stream_t stream, const float* x, size_t npix, i
     MPG_LAUNCH_CHECK("bn_train_fwd");
 }
 
+static int bn_train_bwd_impl(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c, const float* batch_mean,
+                             const float* batch_var, const float* gamma, float eps, float* dx, float* dgamma, float* dbeta,
+                             float* amax, float* partials);
+
 extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
                                 const float* batch_mean, const float* batch_var, const float* gamma, float eps,
                                 float* dx, float* dgamma, float* dbeta, float* amax) {
+    return bn_train_bwd_impl(stream, dy, x, npix, c, batch_mean, batch_var, gamma, eps, dx, dgamma, dbeta, amax, nullptr);
+}
+
+extern "C" int mpg_bn_train_bwd_ordered(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c,
+                                        const float* batch_mean, const float* batch_var, const float* gamma, float eps,
+                                        float* dx, float* dgamma, float* dbeta, float* amax, float* partials,
+                                        size_t partials_floats) {
+    MPG_REQUIRE(partials != nullptr && partials_floats >= mpg_bn_partials_floats(c), "mpg_bn_train_bwd_ordered: partials buffer too small");
+    return bn_train_bwd_impl(stream, dy, x, npix, c, batch_mean, batch_var, gamma, eps, dx, dgamma, dbeta, amax, partials);
+}
+
+static int bn_train_bwd_impl(mpg_stream_t stream, const float* dy, const float* x, size_t npix, int c, const float* batch_mean,
+                             const float* batch_var, const float* gamma, float eps, float* dx, float* dgamma, float* dbeta,
+                             float* amax, float* partials) {
     MPG_REQUIRE(dy && x && batch_mean && batch_var && gamma && dx && dgamma && dbeta,
                 "mpg_bn_train_bwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_bwd: bad shape");
@@ -1049,7 +1067,9 @@ extern "C" int mpg_bn_train_bwd(mpg_stream_t stream, const float* dy, const floa
     }
     if (e == hipSuccess && amax != nullptr) e = mpg::zero_async(amax, sizeof(float), s);
     if (e != hipSuccess) return mpg::hip_check(e, "mpg_bn_train_bwd: memset");
-    launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma);
+    const int nb = launch_chan_sum<2>(s, dy, x, npix, c, batch_mean, batch_var, 0.f, eps, dbeta, dgamma, partials);
+    if (partials != nullptr)      // the blocks' sums in a fixed order (and no atomics queueing on 2 c addresses)
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 15) / 16), dim3(256), 0, s, (const float2*)partials, nb, c, dbeta, dgamma);
     const size_t total = npix * c;
     unsigned g = grid_for(total);
     if (amax != nullptr && g > AMAX_GRID) g = AMAX_GRID;

@@ -138,9 +138,11 @@ def bn_train_bwd(dy, x, mean, var, gamma, eps=1e-3, want_amax=False):
     dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
     dgamma, dbeta = dgb[0], dgb[1]
     amax = torch.empty((), dtype=torch.float32, device=x.device) if want_amax else None
-    _lib.check(lib.mpg_bn_train_bwd(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, _ptr(mean), _ptr(var),
-                                    _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
-                                    _ptr(amax) if want_amax else None), "mpg_bn_train_bwd")
+    nfl = lib.mpg_bn_partials_floats(c)
+    partials = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_bn_train_bwd_ordered(_stream(), _ptr(dy), _ptr(x), x.numel() // c, c, _ptr(mean), _ptr(var),
+                                            _ptr(_cont(gamma, "gamma")), float(eps), _ptr(dx), _ptr(dgamma), _ptr(dbeta),
+                                            _ptr(amax) if want_amax else None, _ptr(partials), nfl), "mpg_bn_train_bwd_ordered")
     return (dx, dgamma, dbeta, amax) if want_amax else (dx, dgamma, dbeta)
 
 
