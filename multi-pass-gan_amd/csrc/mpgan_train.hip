@@ -997,8 +997,10 @@ static int bn_train_fwd_impl(mpg_stream_t stream, const float* x, size_t npix, i
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_fwd: bad shape");
     MPG_REQUIRE(act >= MPG_ACT_NONE && act <= MPG_ACT_TANH, "mpg_bn_train_fwd: bad activation %d", act);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (batch_var == batch_mean + c) {
+    hipError_t e = hipSuccess;
+    if (partials != nullptr) {
+        // ordered form: sum_partials_kernel writes every sum, nothing to clear
+    } else if (batch_var == batch_mean + c) {
         e = mpg::zero_async(batch_mean, (size_t)2 * c * sizeof(float), s);
     } else {
         e = mpg::zero_async(batch_mean, (size_t)c * sizeof(float), s);
@@ -1058,8 +1060,10 @@ static int bn_train_bwd_impl(mpg_stream_t stream, const float* dy, const float* 
                 "mpg_bn_train_bwd: null pointer");
     MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_bn_train_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e;
-    if (dbeta == dgamma + c) {
+    hipError_t e = hipSuccess;
+    if (partials != nullptr) {
+        // ordered form: sum_partials_kernel writes every sum, nothing to clear
+    } else if (dbeta == dgamma + c) {
         e = mpg::zero_async(dgamma, (size_t)2 * c * sizeof(float), s);
     } else {
         e = mpg::zero_async(dgamma, (size_t)c * sizeof(float), s);
