@@ -304,6 +304,9 @@ int mpg_fc_forward(mpg_stream_t stream, const float* x, int rows, int k, const f
                    float wscale, const float* bias, int act, float leak, float* y);
 /* out[c] = sum over pixels of x[p, c]  (bias gradient, GAN.py:683) */
 int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix, int c, float* out);
+/* ... with the blocks' sums added in a fixed order: partials holds >= mpg_bn_partials_floats(c) + c floats */
+int mpg_channel_sum_ordered(mpg_stream_t stream, const float* x, size_t npix, int c, float* out, float* partials,
+                            size_t partials_floats);
 /* tf.contrib.layers.batch_norm(is_training=True) (GAN.py:110): batch mean / biased variance over
  * all pixels, y = act((x - mean) * rsqrt(var + eps) * gamma + beta); the moments are returned, and
  * the moving averages (the UPDATE_OPS, multipassGAN-4x.py:773-776) are advanced in place when

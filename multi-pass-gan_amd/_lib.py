@@ -137,6 +137,7 @@ PROTOTYPES = {
     "mpg_conv2d_dgrad": (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mpg_fc_forward": (_I, [_P, _P, _I, _I, _P, _I, _F, _P, _I, _F, _P]),
     "mpg_channel_sum": (_I, [_P, _P, _Z, _I, _P]),
+    "mpg_channel_sum_ordered": (_I, [_P, _P, _Z, _I, _P, _P, _Z]),
     "mpg_bn_train_fwd": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _F]),
     "mpg_bn_partials_floats": (_Z, [_I]),
     "mpg_bn_train_fwd_ordered": (_I, [_P, _P, _Z, _I, _P, _P, _F, _I, _F, _P, _P, _P, _P, _P, _F, _P, _Z]),

@@ -968,6 +968,20 @@ extern "C" int mpg_channel_sum(mpg_stream_t stream, const float* x, size_t npix,
     MPG_LAUNCH_CHECK("chan_sum_kernel");
 }
 
+// ... with the blocks' sums kept in `partials` (mpg_bn_partials_floats(c) floats; the second float of a pair receives a
+// copy) and added in a fixed order
+extern "C" int mpg_channel_sum_ordered(mpg_stream_t stream, const float* x, size_t npix, int c, float* out, float* partials,
+                                       size_t partials_floats) {
+    MPG_REQUIRE(x && out && partials, "mpg_channel_sum_ordered: null pointer");
+    MPG_REQUIRE(npix >= 1 && c >= 1, "mpg_channel_sum_ordered: bad shape");
+    MPG_REQUIRE(partials_floats >= (size_t)CHAN_SUM_MAX_BLOCKS * c * 2 + (size_t)c, "mpg_channel_sum_ordered: partials buffer too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* spare = partials + (size_t)CHAN_SUM_MAX_BLOCKS * c * 2;      // sum_partials_kernel writes two vectors: the second goes here
+    const int nb = launch_chan_sum<0>(s, x, nullptr, npix, c, nullptr, nullptr, 0.f, 0.f, out, nullptr, partials);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 15) / 16), dim3(256), 0, s, (const float2*)partials, nb, c, out, spare);
+    MPG_LAUNCH_CHECK("chan_sum_kernel (ordered)");
+}
+
 extern "C" size_t mpg_bn_partials_floats(int c) { return c >= 1 ? (size_t)CHAN_SUM_MAX_BLOCKS * c * 2 : 0; }
 
 static int bn_train_fwd_impl(mpg_stream_t stream, const float* x, size_t npix, int c, const float* gamma, const float* beta,

@@ -105,7 +105,10 @@ def channel_sum(x):
     x = _cont(x, "x")
     c = x.shape[-1]
     out = torch.empty((c,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mpg_channel_sum(_stream(), _ptr(x), x.numel() // c, c, _ptr(out)), "mpg_channel_sum")
+    nfl = lib.mpg_bn_partials_floats(c) + c
+    partials = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mpg_channel_sum_ordered(_stream(), _ptr(x), x.numel() // c, c, _ptr(out), _ptr(partials), nfl),
+               "mpg_channel_sum_ordered")
     return out
 
 
