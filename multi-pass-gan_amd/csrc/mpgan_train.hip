@@ -329,12 +329,21 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float2* __restr
     const int tid = threadIdx.x, cl = tid & 15, seg = tid >> 4;
     const int ch = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f;
-    if (ch < c)
-        for (int b = seg; b < nblocks; b += 16) {
+    if (ch < c) {
+        int b = seg;
+        for (; b + 7 * 16 < nblocks; b += 8 * 16) {          // eight loads in flight, added in block order
+            float2 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = partials[(size_t)(b + 16 * u) * c + ch];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s0 += p[u].x; s1 += p[u].y; }
+        }
+        for (; b < nblocks; b += 16) {
             const float2 p = partials[(size_t)b * c + ch];
             s0 += p.x;
             s1 += p.y;
         }
+    }
     red[tid] = make_float2(s0, s1);
     __syncthreads();
     if (seg == 0 && ch < c) {
