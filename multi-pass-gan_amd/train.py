@@ -52,6 +52,18 @@ def _mfma_conv(x, w, wscale, prec, bias=None, act=None, leak=0.2, pad_hi=0, resc
     outs = []
     if not rescale:
         amax = None
+        if isinstance(x, torch.Tensor):
+            # a block's input feeds two convolutions (first conv and 1x1 shortcut): the second one finds the G8 form the first
+            # one made, on the tensor itself (valid while the tensor is neither rewritten in place nor another storage)
+            x = x.contiguous()
+            tag = getattr(x, "_mpg_g8", None)
+            if tag is None or tag[1] != x._version or tag[2] != x.data_ptr() or tag[3] != tuple(x.shape):
+                tag = (ops.to_g8(x, 0, x.shape[3], ops.flavour_for(prec)), x._version, x.data_ptr(), tuple(x.shape))
+                try:
+                    x._mpg_g8 = tag
+                except AttributeError:      # a tensor type that takes no attributes: convert every time
+                    pass
+            x = tag[0]
     elif isinstance(x, torch.Tensor):
         amax = ops.absmax(x) if amax is None else amax
         x = ops.to_g8(x.contiguous(), 0, x.shape[3], ops.flavour_for(prec), amax=amax)
