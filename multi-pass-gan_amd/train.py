@@ -179,28 +179,52 @@ class ConvLayerFn(torch.autograd.Function):
 #   dw = wgrad(x, dy)    : dx = dgrad(dy, G)     d(dy) = conv(x, G)
 # so three Functions that call each other give gradients of any order from the same kernels.
 # ----------------------------------------------------------------------------------------------
+def _scaled_g8(t, prec):
+    """(G8 of t scaled by the power of two of its abs-max, the abs-max), kept on the tensor: a gradient that enters both the
+    data- and the weight-gradient convolution of a layer (or a second-order forward and its weight gradient) is reduced
+    and converted once.  Valid while the tensor is neither rewritten in place nor another storage."""
+    tag = getattr(t, "_mpg_sg8", None)
+    if tag is None or tag[2] != t._version or tag[3] != t.data_ptr() or tag[4] != tuple(t.shape):
+        tc = t.detach().contiguous()
+        am = ops.absmax(tc)
+        tag = (ops.to_g8(tc, 0, tc.shape[3], ops.flavour_for(prec), amax=am), am, t._version, t.data_ptr(), tuple(t.shape))
+        try:
+            t._mpg_sg8 = tag
+        except AttributeError:
+            pass
+    return tag[0], tag[1]
+
+
 def _conv_fwd(x, w, b, cfg):
+    """x may be the autograd tensor itself (its scaled G8 form is cached on it); w, b detached"""
     kh, kw, cin, cout = w.shape
     if cfg.get("fc"):
-        return train_ops.fc_forward(x.reshape(x.shape[0], cin), w.reshape(cin, cout), cfg["wscale"], b).reshape(
-            x.shape[0], 1, 1, cout)
+        xd = x.detach()
+        return train_ops.fc_forward(xd.reshape(xd.shape[0], cin), w.reshape(cin, cout), cfg["wscale"], b).reshape(
+            xd.shape[0], 1, 1, cout)
     if _mfma_ok(kh, kw, cout, cfg["stride"]):
-        return _mfma_conv(x.contiguous(), w.contiguous(), cfg["wscale"], cfg["prec"], b, rescale=bool(cfg.get("rescale_fwd")))
-    return ops.conv2d_direct(x.contiguous(), w.contiguous(), cfg["stride"], cfg["wscale"], None, b)
+        if cfg.get("rescale_fwd") and x.dim() == 4:
+            g8, am = _scaled_g8(x, cfg["prec"])
+            return _mfma_conv(g8, w.contiguous(), cfg["wscale"], cfg["prec"], b, rescale=True, amax=am)
+        return _mfma_conv(x.detach().contiguous(), w.contiguous(), cfg["wscale"], cfg["prec"], b)
+    return ops.conv2d_direct(x.detach().contiguous(), w.contiguous(), cfg["stride"], cfg["wscale"], None, b)
 
 
 def _conv_dgrad(dy, w, cfg, hw):
     kh, kw, cin, cout = w.shape
     if _mfma_ok(kh, kw, cin, cfg["stride"]) and not cfg.get("fc"):
-        return _mfma_conv(dy.contiguous(), w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), cfg["wscale"], cfg["prec"],
-                          pad_hi=1, rescale=True)
-    return train_ops.conv2d_dgrad(dy, w, hw, cfg["stride"], cfg["wscale"])
+        g8, am = _scaled_g8(dy, cfg["prec"])
+        return _mfma_conv(g8, w.flip(0, 1).permute(0, 1, 3, 2).contiguous(), cfg["wscale"], cfg["prec"],
+                          pad_hi=1, rescale=True, amax=am)
+    return train_ops.conv2d_dgrad(dy.detach(), w, hw, cfg["stride"], cfg["wscale"])
 
 
 def _conv_wgrad(x, dy, cfg, kh, kw):
     if train_ops.wgrad_mfma_ok(kh, kw, cfg["stride"]) and not cfg.get("fc"):
-        return train_ops.conv2d_wgrad_mfma(x, dy, kh, kw, cfg["wscale"], _wgrad_prec(cfg["prec"]))
-    return train_ops.conv2d_wgrad(x, dy, kh, kw, cfg["stride"], cfg["wscale"])
+        xg, xam = _scaled_g8(x, cfg["prec"])
+        dg, dam = _scaled_g8(dy, cfg["prec"])
+        return train_ops.conv2d_wgrad_g8(xg, dg, kh, kw, cfg["wscale"], _wgrad_prec(cfg["prec"]), xam, dam)
+    return train_ops.conv2d_wgrad(x.detach(), dy.detach(), kh, kw, cfg["stride"], cfg["wscale"])
 
 
 class ConvFn(torch.autograd.Function):
@@ -210,7 +234,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, b, cfg):
         ctx.save_for_backward(x, w)
         ctx.cfg, ctx.has_bias = cfg, b is not None
-        return _conv_fwd(x.detach(), w.detach(), b.detach() if b is not None else None, cfg)
+        return _conv_fwd(x, w.detach(), b.detach() if b is not None else None, cfg)
 
     @staticmethod
     def backward(ctx, dy):
@@ -226,7 +250,7 @@ class ConvDgradFn(torch.autograd.Function):
     def forward(ctx, dy, w, cfg, hw):
         ctx.save_for_backward(dy, w)
         ctx.cfg = cfg
-        return _conv_dgrad(dy.detach(), w.detach(), cfg, hw)
+        return _conv_dgrad(dy, w.detach(), cfg, hw)
 
     @staticmethod
     def backward(ctx, g):
@@ -242,7 +266,7 @@ class ConvWgradFn(torch.autograd.Function):
     def forward(ctx, x, dy, cfg, kh, kw):
         ctx.save_for_backward(x, dy)
         ctx.cfg = cfg
-        return _conv_wgrad(x.detach(), dy.detach(), cfg, kh, kw)
+        return _conv_wgrad(x, dy, cfg, kh, kw)
 
     @staticmethod
     def backward(ctx, gw):
