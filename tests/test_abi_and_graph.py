@@ -185,9 +185,10 @@ def test_architecture_tables(mpg):
 
 
 def test_no_packed_fp32_valu(mpg):
-    """The device code holds no packed-fp32 VALU instruction: a wave executing v_pk_fma_f32 next to an MFMA wave of
-    another stream was measured to return wrong sums on MI355X (profiles/r02/packed_fp32_mfma_interference.md), so the
-    library is built with -fno-slp-vectorize -fno-vectorize.  Disassembles the gfx950 code object of the built library."""
+    """The device code holds no packed-fp32 VALU instruction: one with op_sel bit 1 set (low half = HIGH word of source 1)
+    next to MFMA waves of another stream was measured to return wrong sums in lanes 48-63 on MI355X
+    (profiles/r03/packed_fp32_followup.md), so the library is built with -fno-slp-vectorize -fno-vectorize.  Disassembles
+    the gfx950 code object of the built library."""
     import os
     import re
     import subprocess

@@ -1,8 +1,8 @@
 """Launches on several HIP streams must reproduce the one-stream results bit for bit.
 
-Guards the finding of profiles/r02/packed_fp32_mfma_interference.md on the hardware itself: a small-layer kernel built
-with packed-fp32 FMAs returned wrong sums for a quarter wave when it shared a SIMD with waves of the one-cout-tile F16F8
-convolution of another stream (the library is therefore built with -fno-slp-vectorize -fno-vectorize, and
+Guards the finding of profiles/r03/packed_fp32_followup.md on the hardware itself: a small-layer kernel built with
+packed-fp32 FMAs (v_pk_fma_f32 .. op_sel:[0,1,0]) returned wrong sums in lanes 48-63 when it shared a CU with MFMA waves of
+another stream's convolution (the library is therefore built with -fno-slp-vectorize -fno-vectorize, and
 tests/test_abi_and_graph.py::test_no_packed_fp32_valu checks the code object)."""
 import numpy as np
 import pytest
